@@ -1,0 +1,183 @@
+/*
+ * oroch_hip.h -- C ABI of the MI355X (gfx950) implementation of Oroch's block
+ * integer-compression path.
+ *
+ * Plain pointers and sizes only.  Unless a parameter says "host", every data
+ * pointer is a DEVICE pointer on the current HIP device and every call is
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default
+ * stream).  Functions return 0 on success, a positive hipError_t value when
+ * the runtime fails, or a negative OROCH_E_* code for argument errors.
+ *
+ * The reference is a header-only C++ template library without an FFI; each
+ * entry point below names the template member(s) of the reference it stands
+ * in for (paths are below /root/reference/oroch).  `include/oroch/` holds the
+ * C++ host templates that keep the reference's names and call into this ABI.
+ *
+ * Element types are selected by a dtype code:
+ *     dtype = 2 * log2(sizeof T) + (unsigned ? 1 : 0)
+ *     0 int8  1 uint8  2 int16  3 uint16  4 int32  5 uint32  6 int64  7 uint64
+ * Origins are passed as the raw bit pattern of T zero-extended to 64 bits.
+ */
+#ifndef OROCH_HIP_H_
+#define OROCH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	OROCH_I8 = 0, OROCH_U8 = 1, OROCH_I16 = 2, OROCH_U16 = 3,
+	OROCH_I32 = 4, OROCH_U32 = 5, OROCH_I64 = 6, OROCH_U64 = 7,
+};
+
+/* encoding_t, integer_codec.h:46-54 */
+enum {
+	OROCH_NAUGHT = 0, OROCH_NORMAL = 1, OROCH_VARINT = 2, OROCH_VARFOR = 3,
+	OROCH_BITPCK = 4, OROCH_BITFOR = 5, OROCH_BITPFR = 6,
+};
+
+enum {
+	OROCH_E_DTYPE = -1,     /* unknown dtype code */
+	OROCH_E_NBITS = -2,     /* nbits outside 1..bits(T) */
+	OROCH_E_BLOCK = -3,     /* unsupported values-per-block */
+	OROCH_E_CAPACITY = -4,  /* destination / workspace too small */
+	OROCH_E_ARGUMENT = -5,  /* null pointer or inconsistent sizes */
+	OROCH_E_NOGPU = -6,     /* no usable HIP device */
+};
+
+/* Values per block of the batch (group) entry points; integer_array.h:44. */
+#define OROCH_BLOCK_VALUES 256
+
+/*
+ * Result of codec selection for one block: the fields of
+ * encoding_metadata<T> (integer_codec.h:95-126) plus the number of bytes the
+ * block occupies in a batch stream.
+ */
+typedef struct oroch_block_desc {
+	uint64_t origin;         /* value_desc.origin, raw bits */
+	uint32_t dataspace;      /* value_desc.dataspace */
+	uint32_t size;           /* align16(align8(metaspace) + dataspace) */
+	uint16_t metaspace;      /* metaspace() = 1 + value_desc.metaspace */
+	uint16_t noutliers;
+	uint16_t nvalues;        /* values in this block */
+	uint8_t encoding;        /* value_desc.encoding */
+	uint8_t nbits;           /* value_desc.nbits */
+	uint8_t index_encoding;  /* outlier_index_desc.encoding (bitpfr only) */
+	uint8_t index_nbits;
+	uint8_t value_encoding;  /* outlier_value_desc.encoding (bitpfr only) */
+	uint8_t value_nbits;
+	uint8_t reserved[4];
+} oroch_block_desc;
+
+/* Library / device set-up.  Selects `device`, verifies it is usable. */
+int oroch_hip_init(int device);
+/* Human-readable text for a return code of this library. */
+const char *oroch_hip_strerror(int code);
+
+/* ---- sizes (host arithmetic) --------------------------------------------- */
+
+/* bitpck_codec::capacity / space, bitpck.h:54-71.  space(0, b) = 0. */
+size_t oroch_bitpck_capacity(unsigned nbits);
+size_t oroch_bitpck_space(size_t nvalues, unsigned nbits);
+
+/* ---- whole-sequence codecs with caller-supplied parameters ---------------- */
+
+/*
+ * bitpck_codec<T>::encode / decode, bitpck.h:227-256, default value codec
+ * (zigzag for signed T, zigzag.h:85-93).  dst of encode needs
+ * oroch_bitpck_space(n, nbits) bytes, 16-byte aligned.
+ */
+int oroch_bitpck_encode(int dtype, const void *src, size_t n, unsigned nbits, void *dst,
+			void *stream);
+int oroch_bitpck_decode(int dtype, const void *src, size_t n, unsigned nbits, void *dst,
+			void *stream);
+
+/*
+ * bitfor_codec<T>::encode / decode, bitfor.h:59-69: bitpck with
+ * origin_codec (origin.h:46-54), no zigzag.
+ */
+int oroch_bitfor_encode(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits,
+			void *dst, void *stream);
+int oroch_bitfor_decode(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits,
+			void *dst, void *stream);
+
+/*
+ * bitpfr_codec<T>::encode, bitpfr.h:95-99 with parameters::value_encode
+ * (bitpfr.h:75-85): packs the low nbits of (v - origin) and appends, in
+ * sequence order, one entry per value that does not fit: the gap-coded
+ * position (offset_codec<size_t,1,false>, offset.h:55-60) into indices[] and
+ * (v - origin) >> nbits into values[] (both uint64_t on the device, room for
+ * `exc_capacity` entries each).  *nexc (device) receives the number of
+ * exceptions found even when it exceeds exc_capacity (nothing is written past
+ * the capacity).  workspace: oroch_bitpfr_workspace(n) bytes.
+ */
+size_t oroch_bitpfr_workspace(size_t n);
+int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits,
+			void *dst, uint64_t *indices, uint64_t *values, size_t exc_capacity,
+			uint64_t *nexc, void *workspace, size_t workspace_bytes, void *stream);
+/*
+ * bitpfr_codec<T>::decode, bitpfr.h:101-124: unpack (decode_basic) then patch
+ * (decode_patch; running sum of gaps, offset.h:62-67).
+ */
+int oroch_bitpfr_decode(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits,
+			const uint64_t *indices, const uint64_t *values, size_t nexc, void *dst,
+			void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- per-block statistics, selection, batch encode / decode --------------- */
+
+/*
+ * integer_codec<T>::select, integer_codec.h:234-384 (with integer_stats.h
+ * :48-53, 74-80), applied independently to every block of
+ * OROCH_BLOCK_VALUES values of src[0..n) (the last block may be short), each
+ * on a fresh metadata object.  desc: device array of ceil(n / block) records.
+ */
+int oroch_group_select(int dtype, const void *src, size_t n, oroch_block_desc *desc,
+		       void *stream);
+
+/* Worst-case bytes of the batch stream for n values; workspace bytes needed. */
+size_t oroch_group_bound(int dtype, size_t n);
+size_t oroch_group_workspace(int dtype, size_t n);
+
+/*
+ * integer_group<T>::encode, integer_group.h:44-60 (aligned = true), for every
+ * block: stream = concatenation of [metadata][zero pad to 8][data] images,
+ * every image starting at a multiple of 16 bytes (zero filled).  offsets:
+ * device array of ceil(n / block) + 1 byte offsets (the last is the stream
+ * length).  dst needs oroch_group_bound() bytes, 16-byte aligned.  If
+ * total_host is not NULL the call waits for the stream and stores the stream
+ * length there.
+ */
+int oroch_group_encode(int dtype, const void *src, size_t n, void *dst, size_t dst_capacity,
+		       uint64_t *offsets, void *workspace, size_t workspace_bytes,
+		       uint64_t *total_host, void *stream);
+
+/*
+ * integer_group<T>::decode, integer_group.h:62-76, for every block of a
+ * stream produced by oroch_group_encode (or by the reference's integer_group
+ * laid out the same way).  src must be readable up to the stream length
+ * rounded up to 16 bytes.
+ */
+int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n, void *dst,
+		       void *stream);
+
+/* ---- host-buffer conveniences (stage through pinned memory, synchronous) -- */
+
+/*
+ * Same as oroch_group_encode / oroch_group_decode with HOST pointers: copies
+ * in over pinned staging buffers, runs the device path, copies the stream and
+ * the offsets back.  dst_capacity >= oroch_group_bound(); offsets_host holds
+ * ceil(n / block) + 1 entries.  Returns the stream length in *total_host.
+ */
+int oroch_group_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
+			    size_t dst_capacity, uint64_t *offsets_host, uint64_t *total_host);
+int oroch_group_decode_host(int dtype, const void *src_host, const uint64_t *offsets_host,
+			    size_t n, void *dst_host);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* OROCH_HIP_H_ */

@@ -1,0 +1,30 @@
+"""oroch_amd -- MI355X (gfx950) implementation of Oroch's block integer-compression path.
+
+The product is `liboroch_hip.so` (hand-written HIP kernels behind the C ABI of
+`include/oroch_hip.h`) and the C++ host templates under `include/oroch/`.  This
+package is the thin Python binding used by the tests and by `bench.py`; torch
+is used only to own device memory and streams.
+"""
+from .capi import (  # noqa: F401
+    BLOCK_VALUES,
+    DTYPES,
+    ENCODING_NAMES,
+    OrochError,
+    bitfor_decode,
+    bitfor_encode,
+    bitpck_decode,
+    bitpck_encode,
+    bitpck_space,
+    bitpfr_decode,
+    bitpfr_encode,
+    dtype_code,
+    group_bound,
+    group_decode,
+    group_decode_host,
+    group_encode,
+    group_encode_host,
+    group_select,
+    group_workspace,
+    lib,
+    library_path,
+)

@@ -1,0 +1,263 @@
+"""ctypes binding of liboroch_hip.so (the C ABI declared in include/oroch_hip.h).
+
+Every function here goes to the HIP library; there is no CPU fallback.  If the
+library is missing the import of this module fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BLOCK_VALUES = 256
+ENCODING_NAMES = ["naught", "normal", "varint", "varfor", "bitpck", "bitfor", "bitpfr"]
+DTYPES = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64]
+
+# numpy record matching struct oroch_block_desc
+DESC_DTYPE = np.dtype([
+    ("origin", "<u8"), ("dataspace", "<u4"), ("size", "<u4"), ("metaspace", "<u2"),
+    ("noutliers", "<u2"), ("nvalues", "<u2"), ("encoding", "u1"), ("nbits", "u1"),
+    ("index_encoding", "u1"), ("index_nbits", "u1"), ("value_encoding", "u1"),
+    ("value_nbits", "u1"), ("reserved", "u1", (4,)),
+])
+assert DESC_DTYPE.itemsize == 32
+
+
+class OrochError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(HERE, "liboroch_hip.so")
+
+
+def _load():
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build it with `make -C oroch_amd/csrc` (or "
+            "__graft_entry__.build()); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    vp, sz, u32, u64, i = C.c_void_p, C.c_size_t, C.c_uint, C.c_uint64, C.c_int
+    sig = {
+        "oroch_hip_init": (i, [i]),
+        "oroch_hip_strerror": (C.c_char_p, [i]),
+        "oroch_bitpck_capacity": (sz, [u32]),
+        "oroch_bitpck_space": (sz, [sz, u32]),
+        "oroch_bitpck_encode": (i, [i, vp, sz, u32, vp, vp]),
+        "oroch_bitpck_decode": (i, [i, vp, sz, u32, vp, vp]),
+        "oroch_bitfor_encode": (i, [i, vp, sz, u64, u32, vp, vp]),
+        "oroch_bitfor_decode": (i, [i, vp, sz, u64, u32, vp, vp]),
+        "oroch_bitpfr_workspace": (sz, [sz]),
+        "oroch_bitpfr_encode": (i, [i, vp, sz, u64, u32, vp, vp, vp, sz, vp, vp, sz, vp]),
+        "oroch_bitpfr_decode": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp, vp, sz, vp]),
+        "oroch_group_select": (i, [i, vp, sz, vp, vp]),
+        "oroch_group_bound": (sz, [i, sz]),
+        "oroch_group_workspace": (sz, [i, sz]),
+        "oroch_group_encode": (i, [i, vp, sz, vp, sz, vp, vp, sz, vp, vp]),
+        "oroch_group_decode": (i, [i, vp, vp, sz, vp, vp]),
+        "oroch_group_encode_host": (i, [i, vp, sz, vp, sz, vp, vp]),
+        "oroch_group_decode_host": (i, [i, vp, vp, sz, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def _check(rc):
+    if rc != 0:
+        raise OrochError("oroch_hip error %d: %s" % (rc, lib.oroch_hip_strerror(rc).decode()))
+
+
+def dtype_code(dt):
+    """dtype code of a numpy dtype or a torch dtype."""
+    if str(dt).startswith("torch."):
+        dt = str(dt).replace("torch.", "")
+    return [np.dtype(d).name for d in DTYPES].index(np.dtype(dt).name)
+
+
+def _raw64(origin, code):
+    bits = 8 << (code >> 1)
+    return int(origin) & ((1 << bits) - 1)
+
+
+def _stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _torch_dtype(code):
+    import torch
+
+    return [torch.int8, torch.uint8, torch.int16, torch.uint16, torch.int32, torch.uint32,
+            torch.int64, torch.uint64][code]
+
+
+def bitpck_space(n, nbits):
+    return lib.oroch_bitpck_space(n, nbits)
+
+
+def _empty_bytes(nbytes, device):
+    import torch
+
+    return torch.empty(max(16, (nbytes + 15) // 16 * 16), dtype=torch.uint8, device=device)
+
+
+def bitpck_encode(x, nbits):
+    """x: 1-D CUDA tensor; returns a uint8 CUDA tensor of bitpck_space bytes."""
+    code = dtype_code(x.dtype)
+    out = _empty_bytes(bitpck_space(x.numel(), nbits), x.device)
+    _check(lib.oroch_bitpck_encode(code, x.data_ptr(), x.numel(), nbits, out.data_ptr(), _stream()))
+    return out[:bitpck_space(x.numel(), nbits)]
+
+
+def bitpck_decode(b, n, nbits, dtype):
+    import torch
+
+    code = dtype_code(dtype)
+    out = torch.empty(n, dtype=_torch_dtype(code), device=b.device)
+    _check(lib.oroch_bitpck_decode(code, b.data_ptr(), n, nbits, out.data_ptr(), _stream()))
+    return out
+
+
+def bitfor_encode(x, origin, nbits):
+    code = dtype_code(x.dtype)
+    out = _empty_bytes(bitpck_space(x.numel(), nbits), x.device)
+    _check(lib.oroch_bitfor_encode(code, x.data_ptr(), x.numel(), _raw64(origin, code), nbits,
+                                   out.data_ptr(), _stream()))
+    return out[:bitpck_space(x.numel(), nbits)]
+
+
+def bitfor_decode(b, n, origin, nbits, dtype):
+    import torch
+
+    code = dtype_code(dtype)
+    out = torch.empty(n, dtype=_torch_dtype(code), device=b.device)
+    _check(lib.oroch_bitfor_decode(code, b.data_ptr(), n, _raw64(origin, code), nbits,
+                                   out.data_ptr(), _stream()))
+    return out
+
+
+def bitpfr_encode(x, origin, nbits, capacity=None):
+    """Returns (packed bytes, gap-coded indices, high parts, nexc) as CUDA tensors / int."""
+    import torch
+
+    code = dtype_code(x.dtype)
+    n = x.numel()
+    cap = n if capacity is None else capacity
+    out = _empty_bytes(bitpck_space(n, nbits), x.device)
+    idx = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
+    val = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
+    nexc = torch.zeros(1, dtype=torch.int64, device=x.device)
+    wsb = lib.oroch_bitpfr_workspace(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    _check(lib.oroch_bitpfr_encode(code, x.data_ptr(), n, _raw64(origin, code), nbits,
+                                   out.data_ptr(), idx.data_ptr(), val.data_ptr(), cap,
+                                   nexc.data_ptr(), ws.data_ptr(), wsb, _stream()))
+    k = int(nexc.item())
+    return out[:bitpck_space(n, nbits)], idx[:min(k, cap)], val[:min(k, cap)], k
+
+
+def bitpfr_decode(b, n, origin, nbits, idx, val, dtype):
+    import torch
+
+    code = dtype_code(dtype)
+    out = torch.empty(n, dtype=_torch_dtype(code), device=b.device)
+    wsb = lib.oroch_bitpfr_workspace(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=b.device)
+    _check(lib.oroch_bitpfr_decode(code, b.data_ptr(), n, _raw64(origin, code), nbits,
+                                   idx.data_ptr(), val.data_ptr(), idx.numel(), out.data_ptr(),
+                                   ws.data_ptr(), wsb, _stream()))
+    return out
+
+
+def group_bound(dtype, n):
+    return lib.oroch_group_bound(dtype_code(dtype), n)
+
+
+def group_workspace(dtype, n):
+    return lib.oroch_group_workspace(dtype_code(dtype), n)
+
+
+def group_select(x):
+    """Per-block selection records as a numpy structured array (DESC_DTYPE)."""
+    import torch
+
+    code = dtype_code(x.dtype)
+    n = x.numel()
+    nb = (n + BLOCK_VALUES - 1) // BLOCK_VALUES
+    desc = torch.zeros(max(nb, 1) * 32, dtype=torch.uint8, device=x.device)
+    _check(lib.oroch_group_select(code, x.data_ptr(), n, desc.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    return desc.cpu().numpy().view(DESC_DTYPE)[:nb]
+
+
+class GroupEncoder:
+    """Pre-allocated buffers for repeated oroch_group_encode calls on one shape."""
+
+    def __init__(self, dtype, n, device):
+        import torch
+
+        self.code = dtype_code(dtype)
+        self.n = n
+        self.nblocks = (n + BLOCK_VALUES - 1) // BLOCK_VALUES
+        self.bound = lib.oroch_group_bound(self.code, n)
+        self.wsb = lib.oroch_group_workspace(self.code, n)
+        self.out = torch.empty(self.bound, dtype=torch.uint8, device=device)
+        self.offsets = torch.empty(self.nblocks + 1, dtype=torch.int64, device=device)
+        self.ws = torch.empty(max(self.wsb, 16), dtype=torch.uint8, device=device)
+
+    def encode(self, x, want_total=False):
+        total = C.c_uint64(0)
+        _check(lib.oroch_group_encode(self.code, x.data_ptr(), self.n, self.out.data_ptr(),
+                                      self.bound, self.offsets.data_ptr(), self.ws.data_ptr(),
+                                      self.wsb, C.byref(total) if want_total else None,
+                                      _stream()))
+        return total.value if want_total else None
+
+
+def group_encode(x):
+    """Returns (stream bytes CUDA uint8 tensor, offsets CUDA int64 tensor)."""
+    enc = GroupEncoder(x.dtype, x.numel(), x.device)
+    total = enc.encode(x, want_total=True)
+    return enc.out[:total], enc.offsets
+
+
+def group_decode(stream, offsets, n, dtype):
+    import torch
+
+    code = dtype_code(dtype)
+    out = torch.empty(n, dtype=_torch_dtype(code), device=stream.device)
+    _check(lib.oroch_group_decode(code, stream.data_ptr(), offsets.data_ptr(), n, out.data_ptr(),
+                                  _stream()))
+    return out
+
+
+def group_encode_host(a):
+    """numpy in, numpy out, through the pinned-staging host entry point."""
+    a = np.ascontiguousarray(a)
+    code = dtype_code(a.dtype)
+    n = a.size
+    nb = (n + BLOCK_VALUES - 1) // BLOCK_VALUES
+    bound = lib.oroch_group_bound(code, n)
+    out = np.empty(bound, np.uint8)
+    offs = np.zeros(nb + 1, np.uint64)
+    total = C.c_uint64(0)
+    _check(lib.oroch_group_encode_host(code, a.ctypes.data, n, out.ctypes.data, bound,
+                                       offs.ctypes.data, C.byref(total)))
+    return out[:total.value].copy(), offs
+
+
+def group_decode_host(stream, offs, n, dtype):
+    stream = np.ascontiguousarray(stream)
+    offs = np.ascontiguousarray(offs, np.uint64)
+    out = np.empty(n, dtype)
+    _check(lib.oroch_group_decode_host(dtype_code(dtype), stream.ctypes.data, offs.ctypes.data, n,
+                                       out.ctypes.data))
+    return out

@@ -1,0 +1,194 @@
+// api.hip -- library set-up, error text and the host-buffer entry points.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/oroch_hip.h"
+
+extern "C" int oroch_hip_init(int device)
+{
+	int count = 0;
+	hipError_t rc = hipGetDeviceCount(&count);
+	if (rc != hipSuccess || count <= 0)
+		return OROCH_E_NOGPU;
+	if (device < 0 || device >= count)
+		return OROCH_E_ARGUMENT;
+	rc = hipSetDevice(device);
+	if (rc != hipSuccess)
+		return int(rc);
+	hipDeviceProp_t prop;
+	rc = hipGetDeviceProperties(&prop, device);
+	if (rc != hipSuccess)
+		return int(rc);
+	// the kernels are compiled for gfx950 (64-lane wavefronts) only
+	if (prop.warpSize != 64 || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return OROCH_E_NOGPU;
+	return 0;
+}
+
+extern "C" const char *oroch_hip_strerror(int code)
+{
+	switch (code) {
+	case 0: return "success";
+	case OROCH_E_DTYPE: return "unknown dtype code";
+	case OROCH_E_NBITS: return "nbits outside the valid range for the element type";
+	case OROCH_E_BLOCK: return "unsupported values-per-block";
+	case OROCH_E_CAPACITY: return "destination or workspace too small";
+	case OROCH_E_ARGUMENT: return "null / misaligned pointer or inconsistent sizes";
+	case OROCH_E_NOGPU: return "no usable gfx950 HIP device";
+	}
+	if (code > 0)
+		return hipGetErrorString(hipError_t(code));
+	return "unknown error";
+}
+
+namespace {
+
+struct dev_buf
+{
+	void *p = nullptr;
+	~dev_buf()
+	{
+		if (p)
+			(void) hipFree(p);
+	}
+	int alloc(size_t bytes)
+	{
+		return int(hipMalloc(&p, bytes ? bytes : 16));
+	}
+};
+
+struct pinned_buf
+{
+	void *p = nullptr;
+	~pinned_buf()
+	{
+		if (p)
+			(void) hipHostFree(p);
+	}
+	int alloc(size_t bytes)
+	{
+		return int(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault));
+	}
+};
+
+// Copies between pageable host memory and the device in chunks staged through
+// two pinned buffers, so the host memcpy of one chunk overlaps the DMA of the
+// other.
+int staged_copy(void *dst, const void *src, size_t bytes, bool to_device, hipStream_t st)
+{
+	const size_t CHUNK = size_t(32) << 20;
+	pinned_buf pin[2];
+	hipEvent_t ev[2];
+	int rc;
+	for (int i = 0; i < 2; i++) {
+		if ((rc = pin[i].alloc(bytes < CHUNK ? bytes : CHUNK)))
+			return rc;
+		if ((rc = int(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming))))
+			return rc;
+	}
+	size_t done = 0;
+	int k = 0;
+	size_t pend_off[2] = {0, 0}, pend_len[2] = {0, 0};
+	bool pending[2] = {false, false};
+	rc = 0;
+	while (done < bytes && rc == 0) {
+		const size_t len = bytes - done < CHUNK ? bytes - done : CHUNK;
+		if (pending[k]) {
+			rc = int(hipEventSynchronize(ev[k]));
+			if (!to_device && rc == 0)
+				std::memcpy(static_cast<char *>(dst) + pend_off[k], pin[k].p, pend_len[k]);
+			pending[k] = false;
+		}
+		if (rc)
+			break;
+		if (to_device) {
+			std::memcpy(pin[k].p, static_cast<const char *>(src) + done, len);
+			rc = int(hipMemcpyAsync(static_cast<char *>(dst) + done, pin[k].p, len,
+						hipMemcpyHostToDevice, st));
+		} else {
+			rc = int(hipMemcpyAsync(pin[k].p, static_cast<const char *>(src) + done, len,
+						hipMemcpyDeviceToHost, st));
+		}
+		if (rc == 0)
+			rc = int(hipEventRecord(ev[k], st));
+		pend_off[k] = done;
+		pend_len[k] = len;
+		pending[k] = true;
+		done += len;
+		k ^= 1;
+	}
+	for (int i = 0; i < 2; i++) {
+		const int j = (k + i) & 1;
+		if (pending[j] && rc == 0) {
+			rc = int(hipEventSynchronize(ev[j]));
+			if (!to_device && rc == 0)
+				std::memcpy(static_cast<char *>(dst) + pend_off[j], pin[j].p, pend_len[j]);
+		}
+	}
+	for (int i = 0; i < 2; i++)
+		(void) hipEventDestroy(ev[i]);
+	return rc;
+}
+
+} // namespace
+
+extern "C" int oroch_group_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
+				       size_t dst_capacity, uint64_t *offsets_host,
+				       uint64_t *total_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (!offsets_host || !total_host || (n && (!src_host || !dst_host)))
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t bound = oroch_group_bound(dtype, n);
+	const size_t nblocks = (n + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
+	dev_buf in, out, offs, ws;
+	int rc;
+	if ((rc = in.alloc(bytes)) || (rc = out.alloc(bound)) ||
+	    (rc = offs.alloc((nblocks + 1) * sizeof(uint64_t))) ||
+	    (rc = ws.alloc(oroch_group_workspace(dtype, n))))
+		return rc;
+	hipStream_t st = nullptr;
+	if ((rc = staged_copy(in.p, src_host, bytes, true, st)))
+		return rc;
+	uint64_t total = 0;
+	rc = oroch_group_encode(dtype, in.p, n, out.p, bound, static_cast<uint64_t *>(offs.p), ws.p,
+				oroch_group_workspace(dtype, n), &total, st);
+	if (rc)
+		return rc;
+	*total_host = total;
+	if (total > dst_capacity)
+		return OROCH_E_CAPACITY;
+	if ((rc = staged_copy(dst_host, out.p, total, false, st)))
+		return rc;
+	return staged_copy(offsets_host, offs.p, (nblocks + 1) * sizeof(uint64_t), false, st);
+}
+
+extern "C" int oroch_group_decode_host(int dtype, const void *src_host,
+				       const uint64_t *offsets_host, size_t n, void *dst_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n == 0)
+		return 0;
+	if (!src_host || !offsets_host || !dst_host)
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t nblocks = (n + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
+	const size_t total = offsets_host[nblocks];
+	dev_buf in, out, offs;
+	int rc;
+	if ((rc = in.alloc(total + 16)) || (rc = out.alloc(bytes)) ||
+	    (rc = offs.alloc((nblocks + 1) * sizeof(uint64_t))))
+		return rc;
+	hipStream_t st = nullptr;
+	if ((rc = staged_copy(in.p, src_host, total, true, st)) ||
+	    (rc = staged_copy(offs.p, offsets_host, (nblocks + 1) * sizeof(uint64_t), true, st)))
+		return rc;
+	rc = oroch_group_decode(dtype, in.p, static_cast<const uint64_t *>(offs.p), n, out.p, st);
+	if (rc)
+		return rc;
+	return staged_copy(dst_host, out.p, bytes, false, st);
+}

@@ -1,0 +1,281 @@
+// common.hpp -- shared device helpers for the gfx950 kernels.
+//
+// Conventions.  A value of element type T (W bits) is carried as a raw W-bit
+// pattern, zero-extended, in the compute type C (uint32_t for W <= 32,
+// uint64_t for W = 64); arithmetic wraps modulo 2^W, which is what the
+// reference's promoted-int arithmetic yields (integer_traits.h:31-59).
+// Wavefronts are 64 lanes; one wavefront owns one block of values.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/oroch_hip.h"
+
+namespace oroch_hip {
+
+constexpr int WAVE = 64;
+
+template <int WBITS, bool SGN>
+struct elem
+{
+	static constexpr int W = WBITS;
+	static constexpr int BYTES = WBITS / 8;
+	static constexpr bool sgn = SGN;
+	using C = std::conditional_t<(WBITS <= 32), uint32_t, uint64_t>;
+	using S = std::conditional_t<WBITS == 8, uint8_t,
+		  std::conditional_t<WBITS == 16, uint16_t,
+		  std::conditional_t<WBITS == 32, uint32_t, uint64_t>>>;
+	static constexpr C MASK = WBITS == 64 ? ~C(0) : C((uint64_t(1) << (WBITS % 64)) - 1);
+	static constexpr C SIGN = C(1) << (WBITS - 1);
+	// XOR-ing this in maps the type's own ordering onto unsigned ordering.
+	static constexpr C FLIP = SGN ? SIGN : C(0);
+};
+
+// Runs `f(elem<..>{})` for the element type named by a dtype code.
+template <typename F>
+inline int dispatch_dtype(int dtype, F &&f)
+{
+	switch (dtype) {
+	case OROCH_I8: return f(elem<8, true>{});
+	case OROCH_U8: return f(elem<8, false>{});
+	case OROCH_I16: return f(elem<16, true>{});
+	case OROCH_U16: return f(elem<16, false>{});
+	case OROCH_I32: return f(elem<32, true>{});
+	case OROCH_U32: return f(elem<32, false>{});
+	case OROCH_I64: return f(elem<64, true>{});
+	case OROCH_U64: return f(elem<64, false>{});
+	}
+	return OROCH_E_DTYPE;
+}
+
+// bitpck.h:54-57 -- values of a given width per 16-byte block.
+__host__ __device__ constexpr uint32_t cap_of(uint32_t nbits)
+{
+	return 128u / nbits;
+}
+
+// Per-width constants: capacity and ceil(2^32 / capacity), so that
+// floor(x / capacity) == umulhi(x, magic) for every x < 2^25.
+struct width_table
+{
+	uint32_t cap[65];
+	uint32_t magic[65];
+};
+
+constexpr width_table make_width_table()
+{
+	width_table t{};
+	t.cap[0] = 1;
+	t.magic[0] = 0;
+	for (uint32_t b = 1; b <= 64; b++) {
+		uint32_t c = 128u / b;
+		t.cap[b] = c;
+		t.magic[b] = uint32_t(((uint64_t(1) << 32) + c - 1) / c);
+	}
+	return t;
+}
+
+#ifdef __HIPCC__
+
+__constant__ const width_table g_width = make_width_table();
+
+__device__ __forceinline__ int lane_id()
+{
+	return int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+}
+
+// integer_traits.h:166-169 -- bit length, 0 for 0.
+__device__ __forceinline__ uint32_t bitlen(uint32_t x)
+{
+	return 32u - uint32_t(__clz(x));
+}
+__device__ __forceinline__ uint32_t bitlen(uint64_t x)
+{
+	return 64u - uint32_t(__clzll(x));
+}
+
+// varint.h:56-59, 66-72 -- bytes of a varint holding a value of bit length nb.
+__device__ __forceinline__ uint32_t vsp_bits(uint32_t nb)
+{
+	uint32_t s = (nb + 6u) / 7u;
+	return s ? s : 1u;
+}
+template <typename C>
+__device__ __forceinline__ uint32_t vsp(C u)
+{
+	return vsp_bits(bitlen(u));
+}
+
+// zigzag.h:47-55 on raw W-bit patterns; identity for unsigned element types.
+template <typename E>
+__device__ __forceinline__ typename E::C zz(typename E::C raw)
+{
+	using C = typename E::C;
+	if constexpr (!E::sgn)
+		return raw;
+	else
+		return ((raw << 1) ^ (C(0) - (raw >> (E::W - 1)))) & E::MASK;
+}
+template <typename E>
+__device__ __forceinline__ typename E::C unzz(typename E::C u)
+{
+	using C = typename E::C;
+	if constexpr (!E::sgn)
+		return u;
+	else
+		return ((u >> 1) ^ (C(0) - (u & 1))) & E::MASK;
+}
+
+// bitpck.h:61-71 -- 16 * ceil(n / capacity(nbits)); nbits in 1..64, n < 2^25.
+__device__ __forceinline__ uint32_t pck_space(uint32_t n, uint32_t nbits)
+{
+	uint32_t c = g_width.cap[nbits];
+	return 16u * __umulhi(n + c - 1u, g_width.magic[nbits]);
+}
+
+// ---- wavefront primitives -------------------------------------------------
+
+__device__ __forceinline__ uint32_t uniform(uint32_t x)
+{
+	return uint32_t(__builtin_amdgcn_readfirstlane(int(x)));
+}
+__device__ __forceinline__ uint64_t uniform(uint64_t x)
+{
+	uint32_t lo = uniform(uint32_t(x)), hi = uniform(uint32_t(x >> 32));
+	return (uint64_t(hi) << 32) | lo;
+}
+__device__ __forceinline__ int uniform(int x)
+{
+	return __builtin_amdgcn_readfirstlane(x);
+}
+
+template <typename V>
+__device__ __forceinline__ V wave_min(V x)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		V y = __shfl_xor(x, o, WAVE);
+		x = y < x ? y : x;
+	}
+	return uniform(x);
+}
+template <typename V>
+__device__ __forceinline__ V wave_max(V x)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		V y = __shfl_xor(x, o, WAVE);
+		x = y > x ? y : x;
+	}
+	return uniform(x);
+}
+template <typename V>
+__device__ __forceinline__ V wave_sum(V x)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		x += __shfl_xor(x, o, WAVE);
+	return uniform(x);
+}
+
+// Inclusive prefix sum over lanes 0..lane.
+__device__ __forceinline__ uint32_t wave_scan_sum(uint32_t x, int lane)
+{
+#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) {
+		uint32_t y = __shfl_up(x, o, WAVE);
+		if (lane >= o)
+			x += y;
+	}
+	return x;
+}
+// Inclusive prefix maximum over lanes 0..lane.
+__device__ __forceinline__ int wave_scan_max(int x, int lane)
+{
+#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) {
+		int y = __shfl_up(x, o, WAVE);
+		if (lane >= o)
+			x = y > x ? y : x;
+	}
+	return x;
+}
+// Value of lane + o, or 0 past the last lane.
+__device__ __forceinline__ uint32_t shfl_down_zero(uint32_t x, int o, int lane)
+{
+	uint32_t y = __shfl_down(x, o, WAVE);
+	return lane + o < WAVE ? y : 0u;
+}
+
+// Orders this wavefront's LDS traffic: what lanes wrote before is visible to
+// what any lane of the same wavefront reads after.  The hardware executes a
+// wavefront's DS instructions in order, so only the compiler needs telling.
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- bit-granular access to a byte image held in LDS -----------------------
+//
+// `img` is a 4-byte aligned LDS array; `bit` an absolute bit position in it.
+
+// OR `nb` (<= 32) bits of `val` (already masked) into the image.
+__device__ __forceinline__ void lds_or_bits(uint32_t *img, uint32_t bit, uint32_t val)
+{
+	uint32_t d = bit >> 5, sh = bit & 31u;
+	uint64_t x = uint64_t(val) << sh;
+	atomicOr(&img[d], uint32_t(x));
+	uint32_t hi = uint32_t(x >> 32);
+	if (hi)
+		atomicOr(&img[d + 1], hi);
+}
+// OR up to 64 bits of `val` (already masked) into the image.
+__device__ __forceinline__ void lds_or_bits(uint32_t *img, uint32_t bit, uint64_t val)
+{
+	uint32_t d = bit >> 5, sh = bit & 31u;
+	uint64_t lo = val << sh;
+	uint32_t top = sh ? uint32_t(val >> (64u - sh)) : 0u;
+	uint32_t w0 = uint32_t(lo), w1 = uint32_t(lo >> 32);
+	if (w0)
+		atomicOr(&img[d], w0);
+	if (w1)
+		atomicOr(&img[d + 1], w1);
+	if (top)
+		atomicOr(&img[d + 2], top);
+}
+
+// Read `nb` (1..32) bits at an absolute bit position.
+__device__ __forceinline__ uint32_t lds_get_bits32(const uint32_t *img, uint32_t bit, uint32_t nb)
+{
+	uint32_t d = bit >> 5, sh = bit & 31u;
+	uint64_t x = (uint64_t(img[d + 1]) << 32) | img[d];
+	uint32_t v = uint32_t(x >> sh);
+	return nb >= 32 ? v : (v & ((1u << nb) - 1u));
+}
+// Read `nb` (1..64) bits at an absolute bit position.
+__device__ __forceinline__ uint64_t lds_get_bits64(const uint32_t *img, uint32_t bit, uint32_t nb)
+{
+	uint32_t d = bit >> 5, sh = bit & 31u;
+	uint64_t lo = (uint64_t(img[d + 1]) << 32) | img[d];
+	uint64_t v = lo >> sh;
+	if (sh)
+		v |= uint64_t(img[d + 2]) << (64u - sh);
+	return nb >= 64 ? v : (v & ((uint64_t(1) << nb) - 1u));
+}
+template <typename C>
+__device__ __forceinline__ C lds_get_bits(const uint32_t *img, uint32_t bit, uint32_t nb)
+{
+	if constexpr (sizeof(C) == 4)
+		return lds_get_bits32(img, bit, nb);
+	else
+		return lds_get_bits64(img, bit, nb);
+}
+
+#endif // __HIPCC__
+
+} // namespace oroch_hip

@@ -1,0 +1,969 @@
+// group.hip -- per-block statistics, codec selection, batch encode and decode.
+//
+// One 64-lane wavefront owns one block of up to 256 values; lane l holds the
+// four consecutive values 4l .. 4l+3 (one 16-byte load per lane for 32-bit
+// types).  A 256-thread workgroup is four independent wavefronts.
+//
+// Reference behaviour reproduced here (paths below /root/reference/oroch):
+//   integer_stats.h:48-53, 74-80, 97-102   min / max / bit-length histogram
+//   integer_codec.h:234-384, 405-496       select (incl. the estimate gate)
+//   integer_codec.h:128-214                metadata bytes
+//   integer_codec.h:386-402, 498-609       encode / decode dispatch, bitpfr lists
+//   integer_group.h:44-76                  [meta][pad to 8][data] framing
+//   bitpck.h:73-201, varint.h:74-115       16-byte block packing, varints
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace oroch_hip {
+
+constexpr int VPL = 4;                     // values per lane
+constexpr int BLOCK = WAVE * VPL;          // values per block (256)
+constexpr int WAVES_PER_WG = 4;
+
+static_assert(BLOCK == OROCH_BLOCK_VALUES, "block size mismatch");
+static_assert(sizeof(oroch_block_desc) == 32, "descriptor layout");
+
+// Wave-uniform outcome of selection for one block.
+template <typename C>
+struct selection
+{
+	uint32_t encoding, nbits;
+	uint32_t metaspace;  // including the encoding byte
+	uint32_t dataspace;
+	uint32_t noutliers;
+	uint32_t ienc, inbits, venc, vnbits;
+	C origin;
+};
+
+// Bytes of LDS one wavefront needs for its block image: the largest image is
+// the raw copy (8 + 256 * sizeof T); the decoder also uses it as value
+// scratch.  Three spare dwords let bit reads run past the last byte.
+template <typename E>
+constexpr int image_bytes()
+{
+	return ((8 + BLOCK * E::BYTES + 15) / 16) * 16 + 16;
+}
+
+// ---- loading a block --------------------------------------------------------
+
+template <typename E>
+__device__ __forceinline__ void load_block(const typename E::S *src, size_t base, int nv, int lane,
+					   typename E::C (&v)[VPL])
+{
+	using S = typename E::S;
+	using C = typename E::C;
+	const S *p = src + base + size_t(lane) * VPL;
+	if (lane * VPL + VPL <= nv) {
+		// one vector load per lane: 4, 8, 16 or 32 bytes
+		if constexpr (E::BYTES == 8) {
+			const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p);
+			ulonglong2 a = q[0], b = q[1];
+			v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+		} else if constexpr (E::BYTES == 4) {
+			uint4 a = *reinterpret_cast<const uint4 *>(p);
+			v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+		} else if constexpr (E::BYTES == 2) {
+			uint2 a = *reinterpret_cast<const uint2 *>(p);
+			v[0] = a.x & 0xffffu; v[1] = a.x >> 16; v[2] = a.y & 0xffffu; v[3] = a.y >> 16;
+		} else {
+			uint32_t a = *reinterpret_cast<const uint32_t *>(p);
+			v[0] = a & 0xffu; v[1] = (a >> 8) & 0xffu; v[2] = (a >> 16) & 0xffu; v[3] = a >> 24;
+		}
+	} else {
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			v[s] = lane * VPL + s < nv ? C(p[s]) : C(0);
+	}
+}
+
+template <typename E>
+__device__ __forceinline__ void store_block(typename E::S *dst, size_t base, int nv, int lane,
+					    const typename E::C (&v)[VPL])
+{
+	using S = typename E::S;
+	S *p = dst + base + size_t(lane) * VPL;
+	if (lane * VPL + VPL <= nv) {
+		if constexpr (E::BYTES == 8) {
+			ulonglong2 *q = reinterpret_cast<ulonglong2 *>(p);
+			q[0] = make_ulonglong2(v[0], v[1]);
+			q[1] = make_ulonglong2(v[2], v[3]);
+		} else if constexpr (E::BYTES == 4) {
+			*reinterpret_cast<uint4 *>(p) = make_uint4(v[0], v[1], v[2], v[3]);
+		} else if constexpr (E::BYTES == 2) {
+			*reinterpret_cast<uint2 *>(p) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+		} else {
+			*reinterpret_cast<uint32_t *>(p) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+		}
+	} else {
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			if (lane * VPL + s < nv)
+				p[s] = S(v[s]);
+	}
+}
+
+// ---- exception positions ------------------------------------------------------
+//
+// For a width b, the exceptions of a block are the values whose delta needs
+// more than b bits.  prev_exception() gives every lane the position of the last
+// exception in lower lanes (-1 if none): offset.h:55-60 with offset 1 stores
+// position - previous - 1, the first one relative to -1.
+__device__ __forceinline__ int prev_exception(const bool (&f)[VPL], int lane)
+{
+	int lp = -1;
+#pragma unroll
+	for (int s = 0; s < VPL; s++)
+		if (f[s])
+			lp = lane * VPL + s;
+	int incl = wave_scan_max(lp, lane);
+	int ex = __shfl_up(incl, 1, WAVE);
+	return lane == 0 ? -1 : ex;
+}
+
+// ---- selection ----------------------------------------------------------------
+
+// integer_codec.h:234-384 for the block held in v[] (nv valid values).
+// hist: 65 dwords of LDS owned by this wavefront.
+template <typename E>
+__device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, uint32_t *hist,
+			     selection<typename E::C> &sel)
+{
+	using C = typename E::C;
+
+	sel.encoding = OROCH_NORMAL;
+	sel.nbits = 0;
+	sel.metaspace = 1;
+	sel.dataspace = 0;
+	sel.noutliers = 0;
+	sel.ienc = sel.venc = OROCH_NORMAL;
+	sel.inbits = sel.vnbits = 0;
+	sel.origin = 0;
+
+	// integer_codec.h:247-253
+	if (nv == 0)
+		return;
+
+	// integer_stats.h:88-95 on order-preserving unsigned keys
+	C kmin = ~C(0), kmax = 0;
+#pragma unroll
+	for (int s = 0; s < VPL; s++) {
+		if (lane * VPL + s < nv) {
+			C k = v[s] ^ E::FLIP;
+			kmin = k < kmin ? k : kmin;
+			kmax = k > kmax ? k : kmax;
+		}
+	}
+	const C mn = wave_min(kmin) ^ E::FLIP;
+	const C mx = wave_max(kmax) ^ E::FLIP;
+	const uint32_t vo = vsp(zz<E>(mn)); // varint bytes of the origin
+
+	// integer_codec.h:255-264
+	if (mn == mx) {
+		sel.encoding = OROCH_NAUGHT;
+		sel.origin = mn;
+		sel.metaspace = 1 + vo;
+		return;
+	}
+
+	// deltas, their bit lengths, and the two varint footprints
+	// (integer_stats.h:97-102, integer_codec.h:483-489)
+	uint32_t ud[VPL];
+	uint32_t sums = 0;
+#pragma unroll
+	for (int s = 0; s < VPL; s++) {
+		bool ok = lane * VPL + s < nv;
+		C d = (v[s] - mn) & E::MASK;
+		ud[s] = bitlen(d);
+		if (ok)
+			sums += vsp(zz<E>(v[s])) + (vsp_bits(ud[s]) << 16);
+	}
+	sums = wave_sum(sums);
+	const uint32_t vis = sums & 0xffffu, vfs = sums >> 16;
+
+	// select_basic, integer_codec.h:422-496; strictly smaller replaces (:413)
+	uint32_t best = uint32_t(nv) * E::BYTES; // data + meta (without encoding byte)
+	uint32_t bmeta0 = 0;
+	{
+		C zmax = mx;
+		if constexpr (E::sgn) {
+			C a = zz<E>(mn), b = zz<E>(mx);
+			zmax = a > b ? a : b;
+		}
+		uint32_t nb = bitlen(zmax);
+		uint32_t total = pck_space(nv, nb) + 1;
+		if (total < best) {
+			best = total;
+			bmeta0 = 1;
+			sel.encoding = OROCH_BITPCK;
+			sel.nbits = nb;
+			sel.origin = 0;
+		}
+	}
+	const uint32_t nbmax = bitlen(C((mx - mn) & E::MASK));
+	{
+		uint32_t total = pck_space(nv, nbmax) + 1 + vo;
+		if (total < best) {
+			best = total;
+			bmeta0 = 1 + vo;
+			sel.encoding = OROCH_BITFOR;
+			sel.nbits = nbmax;
+			sel.origin = mn;
+		}
+		if (vis < best) {
+			best = vis;
+			bmeta0 = 0;
+			sel.encoding = OROCH_VARINT;
+			sel.nbits = 0;
+			sel.origin = 0;
+		}
+		if (vfs + vo < best) {
+			best = vfs + vo;
+			bmeta0 = vo;
+			sel.encoding = OROCH_VARFOR;
+			sel.nbits = 0;
+			sel.origin = mn;
+		}
+	}
+	sel.metaspace = 1 + bmeta0;
+	sel.dataspace = best - bmeta0;
+
+	// integer_codec.h:271-272
+	if (nv < 5)
+		return;
+
+	// ---- patched frame of reference, integer_codec.h:280-383 ----
+	// histogram of bit lengths into LDS, then lane l looks after width b = l + 1
+	hist[lane] = 0;
+	if (lane == 0)
+		hist[64] = 0;
+	wave_sync();
+#pragma unroll
+	for (int s = 0; s < VPL; s++)
+		if (lane * VPL + s < nv)
+			atomicAdd(&hist[ud[s]], 1u);
+	wave_sync();
+	const uint32_t b = uint32_t(lane) + 1;
+	const uint32_t hb = hist[b];
+	wave_sync();
+
+	// values longer than b bits: suffix sum of the histogram, shifted by one
+	uint32_t sfx = hb;
+#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1)
+		sfx += shfl_down_zero(sfx, o, lane);
+	const uint32_t nout = shfl_down_zero(sfx, 1, lane);
+	// varint bytes of the high parts: sum over j >= 0 of nout(b + 7j)
+	// (each value of bit length k > b costs ceil((k - b) / 7) bytes, :308-312)
+	uint32_t valvar = nout;
+	valvar += shfl_down_zero(valvar, 7, lane);
+	valvar += shfl_down_zero(valvar, 14, lane);
+	valvar += shfl_down_zero(valvar, 28, lane);
+	valvar += shfl_down_zero(valvar, 56, lane);
+
+	const bool active = b < nbmax && hb != 0;
+	const uint32_t basic_meta = 1 + vo;
+	const uint32_t bw = active ? b : 1u;
+	const uint32_t xmeta = 2 + vsp_bits(bitlen(nout));
+	const uint32_t valpck = pck_space(nout, active ? nbmax - b : 1u);
+	const uint32_t venc = valpck < valvar ? OROCH_BITPCK : OROCH_VARINT;
+	const uint32_t vdata = valpck < valvar ? valpck : valvar;
+	uint32_t indmin = pck_space(nout, 1);
+	indmin = indmin > uint32_t(nv) ? uint32_t(nv) : indmin;
+	const uint32_t fixed = basic_meta + xmeta + pck_space(nv, bw) + vdata;
+	const uint32_t est = fixed + indmin;
+
+	// Replay of the reference's ascending loop.  `best` only shrinks, so a
+	// width failing the gate (:327-335) against the initial value fails later.
+	uint64_t cand = __ballot(active && est < best);
+	while (cand) {
+		const int L = __builtin_ctzll(cand);
+		cand &= cand - 1;
+		const uint32_t estL = uint32_t(__builtin_amdgcn_readlane(int(est), L));
+		if (estL >= best)
+			continue;
+		const uint32_t bL = uint32_t(L) + 1;
+		const uint32_t noutL = uint32_t(__builtin_amdgcn_readlane(int(nout), L));
+
+		// index gaps of this width's exceptions, :338-351
+		bool f[VPL];
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			f[s] = lane * VPL + s < nv && ud[s] > bL;
+		int prev = prev_exception(f, lane);
+		uint32_t gmax = 0, gsum = 0;
+#pragma unroll
+		for (int s = 0; s < VPL; s++) {
+			if (f[s]) {
+				int pos = lane * VPL + s;
+				uint32_t gap = uint32_t(pos - prev - 1);
+				prev = pos;
+				gmax = gap > gmax ? gap : gmax;
+				gsum += vsp_bits(bitlen(gap));
+			}
+		}
+		// one reduction for both: max in the high half, sum in the low half
+		// does not combine, so two passes
+		gmax = wave_max(gmax);
+		const uint32_t indvar = wave_sum(gsum);
+		uint32_t indnbits = bitlen(gmax);
+		indnbits = indnbits ? indnbits : 1u;
+		const uint32_t indpck = pck_space(noutL, indnbits);
+		const uint32_t ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
+		const uint32_t idata = indpck < indvar ? indpck : indvar;
+
+		const uint32_t fixedL = uint32_t(__builtin_amdgcn_readlane(int(fixed), L));
+		const uint32_t required = fixedL + idata;
+		if (required < best) {
+			best = required;
+			const uint32_t xm = uint32_t(__builtin_amdgcn_readlane(int(xmeta), L));
+			sel.encoding = OROCH_BITPFR;
+			sel.origin = mn;
+			sel.nbits = bL;
+			sel.noutliers = noutL;
+			sel.venc = uint32_t(__builtin_amdgcn_readlane(int(venc), L));
+			sel.vnbits = nbmax - bL;
+			sel.ienc = ienc;
+			sel.inbits = indnbits;
+			sel.metaspace = 1 + basic_meta + xm;
+			sel.dataspace = required - basic_meta - xm;
+		}
+	}
+}
+
+template <typename C>
+__device__ __forceinline__ uint32_t stream_size(const selection<C> &sel)
+{
+	return (((sel.metaspace + 7u) & ~7u) + sel.dataspace + 15u) & ~15u;
+}
+
+template <typename C>
+__device__ __forceinline__ void put_desc(oroch_block_desc *d, const selection<C> &sel, int nv)
+{
+	// 32 bytes as two 16-byte stores
+	uint32_t w[8];
+	w[0] = uint32_t(uint64_t(sel.origin));
+	w[1] = uint32_t(uint64_t(sel.origin) >> 32);
+	w[2] = sel.dataspace;
+	w[3] = stream_size(sel);
+	w[4] = sel.metaspace | (sel.noutliers << 16);
+	w[5] = uint32_t(nv) | (sel.encoding << 16) | (sel.nbits << 24);
+	w[6] = sel.ienc | (sel.inbits << 8) | (sel.venc << 16) | (sel.vnbits << 24);
+	w[7] = 0;
+	uint4 *q = reinterpret_cast<uint4 *>(d);
+	q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+	q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+template <typename C>
+__device__ __forceinline__ void get_desc(const oroch_block_desc *d, selection<C> &sel)
+{
+	const uint4 *q = reinterpret_cast<const uint4 *>(d);
+	uint4 a = q[0], b = q[1];
+	sel.origin = C((uint64_t(uniform(a.y)) << 32) | uniform(a.x));
+	sel.dataspace = uniform(a.z);
+	uint32_t w4 = uniform(b.x), w5 = uniform(b.y), w6 = uniform(b.z);
+	sel.metaspace = w4 & 0xffffu;
+	sel.noutliers = w4 >> 16;
+	sel.encoding = (w5 >> 16) & 0xffu;
+	sel.nbits = w5 >> 24;
+	sel.ienc = w6 & 0xffu;
+	sel.inbits = (w6 >> 8) & 0xffu;
+	sel.venc = (w6 >> 16) & 0xffu;
+	sel.vnbits = w6 >> 24;
+}
+
+// ---- building the block image in LDS --------------------------------------------
+
+// varint.h:74-83 into a byte image; returns the new position.
+__device__ __forceinline__ uint32_t put_varint(uint8_t *img, uint32_t pos, uint64_t u)
+{
+	while (u >= 0x80) {
+		img[pos++] = uint8_t(u | 0x80);
+		u >>= 7;
+	}
+	img[pos++] = uint8_t(u);
+	return pos;
+}
+
+// Builds [meta][pad to 8][data] (integer_group.h:44-60) for the block in v[]
+// into `img` (LDS, 16-byte aligned, zero filled here) and returns its length.
+template <typename E>
+__device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane,
+				 const selection<typename E::C> &sel, uint32_t *img)
+{
+	using C = typename E::C;
+	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+	const uint32_t doff = (sel.metaspace + 7u) & ~7u;
+	const uint32_t total = doff + sel.dataspace;
+	const uint32_t total16 = (total + 15u) & ~15u;
+
+	for (uint32_t o = uint32_t(lane) * 16u; o < total16; o += WAVE * 16u)
+		*reinterpret_cast<uint4 *>(img8 + o) = make_uint4(0, 0, 0, 0);
+	wave_sync();
+
+	// metadata, integer_codec.h:128-151, 177-182, 196-204
+	if (lane == 0) {
+		uint32_t p = 0;
+		img8[p++] = uint8_t(sel.encoding);
+		switch (sel.encoding) {
+		case OROCH_NAUGHT:
+		case OROCH_VARFOR:
+			p = put_varint(img8, p, uint64_t(zz<E>(sel.origin)));
+			break;
+		case OROCH_BITPFR:
+		case OROCH_BITFOR:
+			p = put_varint(img8, p, uint64_t(zz<E>(sel.origin)));
+			img8[p++] = uint8_t(sel.nbits);
+			break;
+		case OROCH_BITPCK:
+			img8[p++] = uint8_t(sel.nbits);
+			break;
+		default:
+			break;
+		}
+		if (sel.encoding == OROCH_BITPFR) {
+			p = put_varint(img8, p, sel.noutliers);
+			img8[p++] = sel.ienc == OROCH_BITPCK ? uint8_t(sel.inbits) : uint8_t(0);
+			img8[p++] = sel.venc == OROCH_BITPCK ? uint8_t(sel.vnbits) : uint8_t(0);
+		}
+	}
+
+	const uint32_t enc = sel.encoding;
+	if (enc == OROCH_NORMAL) {
+		// normal.h:42-49
+		typename E::S *raw = reinterpret_cast<typename E::S *>(img8 + doff);
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			if (lane * VPL + s < nv)
+				raw[lane * VPL + s] = typename E::S(v[s]);
+	} else if (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) {
+		// bitpck.h:73-128: value k of a 16-byte block at bit k * nbits
+		const uint32_t nb = sel.nbits;
+		const uint32_t cap = g_width.cap[nb], magic = g_width.magic[nb];
+		const C low = nb >= uint32_t(E::W) ? E::MASK : C((C(1) << (nb % E::W)) - 1);
+		C u[VPL];
+		bool f[VPL];
+#pragma unroll
+		for (int s = 0; s < VPL; s++) {
+			const bool ok = lane * VPL + s < nv;
+			u[s] = enc == OROCH_BITPCK ? zz<E>(v[s]) : C((v[s] - sel.origin) & E::MASK);
+			f[s] = ok && enc == OROCH_BITPFR && (u[s] & ~low) != 0;
+			if (ok) {
+				const uint32_t pos = uint32_t(lane * VPL + s);
+				const uint32_t blk = __umulhi(pos, magic);
+				const uint32_t k = pos - blk * cap;
+				lds_or_bits(img, doff * 8u + blk * 128u + k * nb, C(u[s] & low));
+			}
+		}
+		if (enc == OROCH_BITPFR) {
+			// exception lists, integer_codec.h:573-580: indices then values,
+			// each bit-packed (element types size_t / unsigned T) or varint
+			int prev = prev_exception(f, lane);
+			uint32_t gap[VPL];
+			C hv[VPL];
+			uint32_t acc = 0; // rank | index bytes << 10 | value bytes << 20
+#pragma unroll
+			for (int s = 0; s < VPL; s++) {
+				gap[s] = 0;
+				hv[s] = 0;
+				if (f[s]) {
+					int pos = lane * VPL + s;
+					gap[s] = uint32_t(pos - prev - 1);
+					prev = pos;
+					hv[s] = u[s] >> nb;
+					acc += 1u + (vsp_bits(bitlen(gap[s])) << 10) + (vsp(hv[s]) << 20);
+				}
+			}
+			uint32_t run = wave_scan_sum(acc, lane) - acc; // exclusive
+			const uint32_t ibase = doff + pck_space(uint32_t(nv), nb);
+			const uint32_t ilen = sel.ienc == OROCH_BITPCK
+						      ? pck_space(sel.noutliers, sel.inbits)
+						      : (wave_sum(acc) >> 10) & 0x3ffu;
+			const uint32_t vbase = ibase + ilen;
+			const uint32_t icap = g_width.cap[sel.inbits ? sel.inbits : 1u];
+			const uint32_t imagic = g_width.magic[sel.inbits ? sel.inbits : 1u];
+			const uint32_t vcap = g_width.cap[sel.vnbits ? sel.vnbits : 1u];
+			const uint32_t vmagic = g_width.magic[sel.vnbits ? sel.vnbits : 1u];
+#pragma unroll
+			for (int s = 0; s < VPL; s++) {
+				if (f[s]) {
+					const uint32_t e = run & 0x3ffu;
+					if (sel.ienc == OROCH_BITPCK) {
+						const uint32_t blk = __umulhi(e, imagic);
+						lds_or_bits(img, ibase * 8u + blk * 128u + (e - blk * icap) * sel.inbits,
+							    gap[s]);
+					} else {
+						put_varint(img8, ibase + ((run >> 10) & 0x3ffu), gap[s]);
+					}
+					if (sel.venc == OROCH_BITPCK) {
+						const uint32_t blk = __umulhi(e, vmagic);
+						lds_or_bits(img, vbase * 8u + blk * 128u + (e - blk * vcap) * sel.vnbits,
+							    hv[s]);
+					} else {
+						put_varint(img8, vbase + (run >> 20), uint64_t(hv[s]));
+					}
+					run += 1u + (vsp_bits(bitlen(gap[s])) << 10) + (vsp(hv[s]) << 20);
+				}
+			}
+		}
+	} else if (enc == OROCH_VARINT || enc == OROCH_VARFOR) {
+		// varint.h:133-139 with zigzag (varint) or origin_codec (varfor)
+		C u[VPL];
+		uint32_t len = 0;
+#pragma unroll
+		for (int s = 0; s < VPL; s++) {
+			u[s] = enc == OROCH_VARINT ? zz<E>(v[s]) : C((v[s] - sel.origin) & E::MASK);
+			if (lane * VPL + s < nv)
+				len += vsp(u[s]);
+		}
+		uint32_t at = doff + wave_scan_sum(len, lane) - len;
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			if (lane * VPL + s < nv)
+				at = put_varint(img8, at, uint64_t(u[s]));
+	}
+	wave_sync();
+	return total;
+}
+
+// Copies an LDS image of `len` bytes to 16-byte aligned global memory.
+__device__ __forceinline__ void flush_image(const uint32_t *img, uint32_t len, uint8_t *dst, int lane)
+{
+	const uint32_t len16 = (len + 15u) & ~15u;
+	const uint8_t *img8 = reinterpret_cast<const uint8_t *>(img);
+	for (uint32_t o = uint32_t(lane) * 16u; o < len16; o += WAVE * 16u)
+		*reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(img8 + o);
+}
+
+// ---- kernels ----------------------------------------------------------------------
+
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select(const typename E::S *src, size_t n,
+								 size_t nblocks, oroch_block_desc *desc,
+								 uint32_t *sizes)
+{
+	__shared__ uint32_t hist[WAVES_PER_WG][80];
+	const int wave = threadIdx.x / WAVE, lane = lane_id();
+	const size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
+	if (blk >= nblocks)
+		return;
+	const size_t base = blk * BLOCK;
+	const int nv = int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
+	typename E::C v[VPL];
+	load_block<E>(src, base, nv, lane, v);
+	selection<typename E::C> sel;
+	select_block<E>(v, nv, lane, hist[wave], sel);
+	if (lane == 0) {
+		if (desc)
+			put_desc(&desc[blk], sel, nv);
+		if (sizes)
+			sizes[blk] = stream_size(sel);
+	}
+}
+
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode(const typename E::S *src, size_t n,
+								 size_t nblocks,
+								 const oroch_block_desc *desc,
+								 const uint64_t *offsets, uint8_t *dst)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
+	const int wave = threadIdx.x / WAVE, lane = lane_id();
+	const size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
+	if (blk >= nblocks)
+		return;
+	const size_t base = blk * BLOCK;
+	const int nv = int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
+	typename E::C v[VPL];
+	load_block<E>(src, base, nv, lane, v);
+	selection<typename E::C> sel;
+	get_desc(&desc[blk], sel);
+	const uint64_t off = uniform(offsets[blk]);
+	const uint32_t len = encode_block<E>(v, nv, lane, sel, image[wave]);
+	flush_image(image[wave], len, dst + off, lane);
+}
+
+// ---- decode -------------------------------------------------------------------------
+
+// varint.h:85-115 at a byte position of an LDS image; advances pos.
+__device__ __forceinline__ uint64_t get_varint(const uint8_t *img, uint32_t &pos)
+{
+	uint64_t value = 0;
+	uint32_t shift = 0;
+	for (;;) {
+		uint32_t byte = img[pos++];
+		if (shift < 64)
+			value |= uint64_t(byte & 0x7fu) << shift;
+		shift += 7;
+		if ((byte & 0x80u) == 0 || shift > 70)
+			break;
+	}
+	return value;
+}
+
+// Decodes `count` varints that start at byte `start` of the image, lanes
+// working on 64 bytes at a time: a byte that ends a value (top bit clear)
+// closes one; every byte ORs its 7 payload bits into its value's slot of
+// `out` (LDS, zero filled by the caller).  Returns the bytes consumed.
+template <typename C>
+__device__ uint32_t varint_list_decode(const uint8_t *img8, uint32_t start, uint32_t limit,
+				       uint32_t count, C *out, int lane)
+{
+	uint32_t done = 0;   // values completed so far
+	uint32_t carry = 0;  // bytes of the open value seen in earlier chunks
+	uint32_t pos = start;
+	while (done < count && pos < limit) {
+		const uint32_t at = pos + uint32_t(lane);
+		const uint32_t byte = at < limit ? img8[at] : 0u;
+		const bool term = (byte & 0x80u) == 0;
+		const uint64_t T = __ballot(term);
+		const uint64_t below = T & ((uint64_t(1) << lane) - 1);
+		const uint32_t r = uint32_t(__popcll(below));
+		const int pt = below ? 63 - __clzll(below) : -1;
+		const uint32_t k = uint32_t(lane - pt - 1) + (pt < 0 ? carry : 0u);
+		const uint32_t vi = done + r;
+		if (vi < count && k * 7u < sizeof(C) * 8u) {
+			C part = C(byte & 0x7fu) << (k * 7u);
+			if (part) {
+				if constexpr (sizeof(C) == 8)
+					atomicOr(reinterpret_cast<unsigned long long *>(&out[vi]),
+						 (unsigned long long) part);
+				else
+					atomicOr(&out[vi], part);
+			}
+		}
+		// how far does this chunk go: up to the terminator that completes
+		// value `count`, else all 64 bytes
+		const uint32_t nterm = uint32_t(__popcll(T));
+		if (done + nterm >= count) {
+			// position of the (count - done)-th terminator
+			uint32_t need = count - done;
+			uint64_t t = T;
+			for (uint32_t i = 1; i < need; i++)
+				t &= t - 1;
+			pos += uint32_t(__builtin_ctzll(t)) + 1u;
+			done = count;
+		} else {
+			const int last = T ? 63 - __clzll(T) : -1;
+			carry = last < 0 ? carry + 64u : uint32_t(63 - last);
+			done += nterm;
+			pos += 64u;
+		}
+	}
+	wave_sync();
+	return pos - start;
+}
+
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *src,
+								 const uint64_t *offsets, size_t n,
+								 size_t nblocks, typename E::S *dst)
+{
+	using C = typename E::C;
+	// image: the block's bytes; vals: one slot per value (list scratch, patches)
+	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
+	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK];
+	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
+	const int wave = threadIdx.x / WAVE, lane = lane_id();
+	const size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
+	if (blk >= nblocks)
+		return;
+	const size_t base = blk * BLOCK;
+	const int nv = int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
+	const uint64_t off = uniform(offsets[blk]);
+	uint32_t len = uint32_t(uniform(offsets[blk + 1]) - off);
+	const uint32_t maxlen = uint32_t(image_bytes<E>() - 16);
+	len = len > maxlen ? maxlen : len;
+	uint32_t *img = image[wave];
+	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+	for (uint32_t o = uint32_t(lane) * 16u; o < len; o += WAVE * 16u)
+		*reinterpret_cast<uint4 *>(img8 + o) = *reinterpret_cast<const uint4 *>(src + off + o);
+	wave_sync();
+
+	// metadata, integer_codec.h:153-175, 184-194, 206-214 (every lane parses)
+	uint32_t p = 0;
+	const uint32_t enc = img8[p++];
+	C origin = 0;
+	uint32_t nb = 0, nout = 0, inb = 0, vnb = 0;
+	if (enc == OROCH_NAUGHT || enc == OROCH_VARFOR || enc == OROCH_BITFOR || enc == OROCH_BITPFR)
+		origin = unzz<E>(C(get_varint(img8, p)) & E::MASK);
+	if (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR)
+		nb = img8[p++];
+	if (enc == OROCH_BITPFR) {
+		nout = uint32_t(get_varint(img8, p));
+		inb = img8[p++];
+		vnb = img8[p++];
+	}
+	const uint32_t doff = (p + 7u) & ~7u; // integer_group.h:70-72
+
+	C v[VPL];
+#pragma unroll
+	for (int s = 0; s < VPL; s++)
+		v[s] = 0;
+
+	// Reject what the encoder never produces instead of reading wild.
+	const bool sane = (nb >= 1 && nb <= uint32_t(E::W)) || !(enc >= OROCH_BITPCK);
+	if (enc == OROCH_NAUGHT) {
+		// naught.h:42-47
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			v[s] = origin;
+	} else if (enc == OROCH_NORMAL) {
+		// normal.h:51-58
+		const typename E::S *raw = reinterpret_cast<const typename E::S *>(img8 + doff);
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			if (lane * VPL + s < nv)
+				v[s] = raw[lane * VPL + s];
+	} else if ((enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) && sane) {
+		// bitpck.h:171-201 as a bit-field read
+		const uint32_t cap = g_width.cap[nb], magic = g_width.magic[nb];
+		C u[VPL];
+#pragma unroll
+		for (int s = 0; s < VPL; s++) {
+			const uint32_t pos = uint32_t(lane * VPL + s);
+			u[s] = 0;
+			if (pos < uint32_t(nv)) {
+				const uint32_t blkn = __umulhi(pos, magic);
+				const uint32_t k = pos - blkn * cap;
+				u[s] = lds_get_bits<C>(img, doff * 8u + blkn * 128u + k * nb, nb) & E::MASK;
+			}
+		}
+		if (enc == OROCH_BITPFR && nout > 0 && nout <= uint32_t(nv) && vnb <= uint32_t(E::W) &&
+		    inb <= 64) {
+			// integer_codec.h:583-609, bitpfr.h:114-124
+			C *val = vals[wave];
+			uint32_t *gp = gaps[wave];
+			const uint32_t ibase = doff + pck_space(uint32_t(nv), nb);
+			for (int i = lane; i < BLOCK; i += WAVE) {
+				val[i] = 0;
+				gp[i] = 0;
+			}
+			wave_sync();
+			uint32_t ilen;
+			if (inb) {
+				const uint32_t icap = g_width.cap[inb], imagic = g_width.magic[inb];
+				for (uint32_t e = uint32_t(lane); e < nout; e += WAVE) {
+					const uint32_t bk = __umulhi(e, imagic);
+					gp[e] = uint32_t(lds_get_bits64(img, ibase * 8u + bk * 128u + (e - bk * icap) * inb,
+								       inb));
+				}
+				ilen = pck_space(nout, inb);
+				wave_sync();
+			} else {
+				ilen = varint_list_decode<uint32_t>(img8, ibase, len, nout, gp, lane);
+			}
+			const uint32_t vbase = ibase + ilen;
+			if (vnb) {
+				const uint32_t vcap = g_width.cap[vnb], vmagic = g_width.magic[vnb];
+				for (uint32_t e = uint32_t(lane); e < nout; e += WAVE) {
+					const uint32_t bk = __umulhi(e, vmagic);
+					val[e] = lds_get_bits<C>(img, vbase * 8u + bk * 128u + (e - bk * vcap) * vnb, vnb);
+				}
+				wave_sync();
+			} else {
+				varint_list_decode<C>(img8, vbase, len, nout, val, lane);
+			}
+			// positions: running sum of gap + 1 (offset.h:62-67); then every
+			// exception hands its high part to the lane owning the position
+			uint32_t carry = 0;
+			C hi[VPL];
+			uint32_t epos[VPL];
+#pragma unroll
+			for (int it = 0; it < VPL; it++) {
+				const uint32_t e = uint32_t(it * WAVE + lane);
+				const uint32_t step = e < nout ? gp[e] + 1u : 0u;
+				const uint32_t incl = wave_scan_sum(step, lane) + carry;
+				carry = uniform(uint32_t(__shfl(incl, WAVE - 1, WAVE)));
+				epos[it] = e < nout ? incl - 1u : ~0u;
+				hi[it] = e < nout ? val[e] : C(0);
+			}
+			wave_sync();
+			// the value scratch now becomes a patch table indexed by position
+			for (int i = lane; i < BLOCK; i += WAVE)
+				val[i] = 0;
+			wave_sync();
+#pragma unroll
+			for (int it = 0; it < VPL; it++)
+				if (epos[it] < uint32_t(BLOCK))
+					val[epos[it]] = C(hi[it] << nb) & E::MASK;
+			wave_sync();
+#pragma unroll
+			for (int s = 0; s < VPL; s++)
+				u[s] |= val[lane * VPL + s];
+		}
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			v[s] = enc == OROCH_BITPCK ? unzz<E>(u[s]) : C((u[s] + origin) & E::MASK);
+	} else if (enc == OROCH_VARINT || enc == OROCH_VARFOR) {
+		// varint.h:141-147
+		C *val = vals[wave];
+		for (int i = lane; i < BLOCK; i += WAVE)
+			val[i] = 0;
+		wave_sync();
+		varint_list_decode<C>(img8, doff, len, uint32_t(nv), val, lane);
+#pragma unroll
+		for (int s = 0; s < VPL; s++) {
+			C u = val[lane * VPL + s] & E::MASK;
+			v[s] = enc == OROCH_VARINT ? unzz<E>(u) : C((u + origin) & E::MASK);
+		}
+	}
+	store_block<E>(dst, base, nv, lane, v);
+}
+
+// ---- host side ----------------------------------------------------------------------
+
+static inline size_t nblocks_of(size_t n)
+{
+	return (n + BLOCK - 1) / BLOCK;
+}
+
+static inline size_t align_up(size_t x, size_t a)
+{
+	return (x + a - 1) / a * a;
+}
+
+struct group_ws
+{
+	oroch_block_desc *desc;
+	uint32_t *sizes;
+	uint64_t *tile_sums;
+	uint64_t *total;
+	size_t bytes;
+};
+
+static group_ws carve_ws(void *ws, size_t n)
+{
+	const size_t nb = nblocks_of(n);
+	const size_t ntiles = (nb + SCAN_TILE - 1) / SCAN_TILE;
+	group_ws w;
+	size_t off = 0;
+	char *p = static_cast<char *>(ws);
+	w.desc = reinterpret_cast<oroch_block_desc *>(p + off);
+	off = align_up(off + nb * sizeof(oroch_block_desc), 256);
+	w.sizes = reinterpret_cast<uint32_t *>(p + off);
+	off = align_up(off + nb * sizeof(uint32_t), 256);
+	w.tile_sums = reinterpret_cast<uint64_t *>(p + off);
+	off = align_up(off + (ntiles + 1) * sizeof(uint64_t), 256);
+	w.total = reinterpret_cast<uint64_t *>(p + off);
+	off = align_up(off + 256, 256);
+	w.bytes = off;
+	return w;
+}
+
+} // namespace oroch_hip
+
+using namespace oroch_hip;
+
+extern "C" size_t oroch_group_bound(int dtype, size_t n)
+{
+	if (dtype < 0 || dtype > 7)
+		return 0;
+	const size_t bytes = size_t(1) << (dtype >> 1);
+	const size_t nb = nblocks_of(n);
+	// per block at most the raw copy behind an 8-byte header, rounded to 16;
+	// a constant block is 16 bytes
+	return nb * align_up(8 + BLOCK * bytes, 16) + 16;
+}
+
+extern "C" size_t oroch_group_workspace(int dtype, size_t n)
+{
+	(void) dtype;
+	return carve_ws(nullptr, n).bytes;
+}
+
+extern "C" int oroch_group_select(int dtype, const void *src, size_t n, oroch_block_desc *desc,
+				  void *stream)
+{
+	if (n && (!src || !desc))
+		return OROCH_E_ARGUMENT;
+	const size_t nb = nblocks_of(n);
+	if (nb == 0)
+		return 0;
+	if (nb > 0x7fffffffu * size_t(WAVES_PER_WG))
+		return OROCH_E_ARGUMENT;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+		hipLaunchKernelGGL(k_select<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
+				   static_cast<const typename E::S *>(src), n, nb, desc,
+				   static_cast<uint32_t *>(nullptr));
+		return int(hipGetLastError());
+	});
+}
+
+extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *dst,
+				  size_t dst_capacity, uint64_t *offsets, void *workspace,
+				  size_t workspace_bytes, uint64_t *total_host, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (!offsets || (n && (!src || !dst || !workspace)))
+		return OROCH_E_ARGUMENT;
+	if ((reinterpret_cast<uintptr_t>(dst) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 15u))
+		return OROCH_E_ARGUMENT;
+	if (dst_capacity < oroch_group_bound(dtype, n) || workspace_bytes < oroch_group_workspace(dtype, n))
+		return OROCH_E_CAPACITY;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const size_t nb = nblocks_of(n);
+	if (nb > 0x7fffffffu * size_t(WAVES_PER_WG))
+		return OROCH_E_ARGUMENT;
+	int rc = 0;
+	if (nb == 0) {
+		rc = int(hipMemsetAsync(offsets, 0, sizeof(uint64_t), st));
+		if (rc == 0 && total_host) {
+			*total_host = 0;
+			rc = int(hipStreamSynchronize(st));
+		}
+		return rc;
+	}
+	group_ws w = carve_ws(workspace, n);
+	rc = dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+		hipLaunchKernelGGL(k_select<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
+				   static_cast<const typename E::S *>(src), n, nb, w.desc, w.sizes);
+		int r = int(hipGetLastError());
+		if (r)
+			return r;
+		r = launch_scan<uint32_t, 0>(w.sizes, nb, w.tile_sums, w.total, offsets, st);
+		if (r)
+			return r;
+		hipLaunchKernelGGL(k_encode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
+				   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
+				   static_cast<uint8_t *>(dst));
+		return int(hipGetLastError());
+	});
+	if (rc == 0 && total_host) {
+		rc = int(hipMemcpyAsync(total_host, offsets + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+		if (rc == 0)
+			rc = int(hipStreamSynchronize(st));
+	}
+	return rc;
+}
+
+extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n,
+				  void *dst, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n && (!src || !dst || !offsets))
+		return OROCH_E_ARGUMENT;
+	if (reinterpret_cast<uintptr_t>(src) & 15u)
+		return OROCH_E_ARGUMENT;
+	const size_t nb = nblocks_of(n);
+	if (nb == 0)
+		return 0;
+	if (nb > 0x7fffffffu * size_t(WAVES_PER_WG))
+		return OROCH_E_ARGUMENT;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+		hipLaunchKernelGGL(k_decode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
+				   static_cast<const uint8_t *>(src), offsets, n, nb,
+				   static_cast<typename E::S *>(dst));
+		return int(hipGetLastError());
+	});
+}

@@ -1,0 +1,521 @@
+// pack.hip -- whole-sequence bit-packing with caller-supplied parameters.
+//
+//   bitpck_codec<T>::encode/decode   bitpck.h:227-256  (zigzag.h:85-93 fused)
+//   bitfor_codec<T>::encode/decode   bitfor.h:59-69    (origin.h:46-54 fused)
+//   bitpfr_codec<T>::encode/decode   bitpfr.h:95-124   (exception lists, offset.h)
+//
+// The output of a width-b packing is a run of independent 16-byte blocks,
+// block j holding values [j*cap, (j+1)*cap), value k at bit k*b of the block
+// read as a 128-bit little-endian integer (bitpck.h:73-128).  A workgroup
+// stages a tile of values (encode) or of packed blocks (decode) in LDS with
+// coalesced global accesses and converts out of LDS.
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace oroch_hip {
+
+constexpr int PK_THREADS = 256;
+constexpr int PK_TILE_VALUES = 4096;   // values staged per tile (upper bound)
+constexpr int PK_MAX_BLOCKS = 1024;    // 16-byte blocks per tile (upper bound)
+
+enum { VC_ZIGZAG = 0, VC_ORIGIN = 1 };
+
+struct pack_geom
+{
+	uint32_t nbits, cap, magic;
+	uint32_t tile_blocks;   // 16-byte blocks per tile
+	uint32_t k0[2], k1[2];  // first / last value overlapping qword 0 / 1 of a block
+};
+
+static pack_geom make_geom(unsigned nbits)
+{
+	pack_geom g;
+	g.nbits = nbits;
+	g.cap = 128u / nbits;
+	g.magic = uint32_t(((uint64_t(1) << 32) + g.cap - 1) / g.cap);
+	uint32_t tb = PK_TILE_VALUES / g.cap;
+	g.tile_blocks = tb > PK_MAX_BLOCKS ? PK_MAX_BLOCKS : (tb ? tb : 1);
+	for (int w = 0; w < 2; w++) {
+		g.k0[w] = (64u * w) / nbits;
+		uint32_t last = (64u * w + 63u) / nbits;
+		g.k1[w] = last > g.cap - 1 ? g.cap - 1 : last;
+	}
+	return g;
+}
+
+template <typename E, int VC>
+__device__ __forceinline__ typename E::C value_encode(typename E::C raw, typename E::C origin)
+{
+	if constexpr (VC == VC_ZIGZAG)
+		return zz<E>(raw);
+	else
+		return (raw - origin) & E::MASK;
+}
+template <typename E, int VC>
+__device__ __forceinline__ typename E::C value_decode(typename E::C u, typename E::C origin)
+{
+	if constexpr (VC == VC_ZIGZAG)
+		return unzz<E>(u & E::MASK);
+	else
+		return (u + origin) & E::MASK;
+}
+
+template <typename E, int VC>
+__global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, size_t n,
+						       size_t nblk, pack_geom g, typename E::C origin,
+						       uint64_t *dst)
+{
+	using C = typename E::C;
+	using S = typename E::S;
+	__shared__ S stage[PK_TILE_VALUES];
+	const C low = g.nbits >= uint32_t(E::W) ? E::MASK : C((C(1) << (g.nbits % E::W)) - 1);
+	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
+	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const size_t b0 = tile * g.tile_blocks;
+		const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
+		const size_t v0 = b0 * g.cap;
+		const uint32_t slots = tb * g.cap;
+		const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
+		for (uint32_t i = threadIdx.x; i < slots; i += PK_THREADS)
+			stage[i] = i < nvals ? S(value_encode<E, VC>(C(src[v0 + i]), origin) & low) : S(0);
+		__syncthreads();
+		for (uint32_t q = threadIdx.x; q < 2 * tb; q += PK_THREADS) {
+			const uint32_t blk = q >> 1, w = q & 1;
+			const S *vals = stage + blk * g.cap;
+			uint64_t acc = 0;
+			for (uint32_t k = g.k0[w]; k <= g.k1[w]; k++) {
+				const uint64_t val = vals[k];
+				const int pos = int(k * g.nbits) - int(64 * w);
+				acc |= pos >= 0 ? val << pos : val >> (-pos);
+			}
+			dst[b0 * 2 + q] = acc;
+		}
+		__syncthreads();
+	}
+}
+
+template <typename E, int VC>
+__global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t n, size_t nblk,
+							 pack_geom g, typename E::C origin,
+							 typename E::S *dst)
+{
+	using C = typename E::C;
+	using S = typename E::S;
+	__shared__ __attribute__((aligned(16))) uint32_t stage[PK_MAX_BLOCKS * 4 + 4];
+	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
+	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const size_t b0 = tile * g.tile_blocks;
+		const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
+		const size_t v0 = b0 * g.cap;
+		const uint32_t slots = tb * g.cap;
+		const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
+		for (uint32_t i = threadIdx.x; i < tb; i += PK_THREADS)
+			reinterpret_cast<uint4 *>(stage)[i] = src[b0 + i];
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < nvals; i += PK_THREADS) {
+			const uint32_t blk = __umulhi(i, g.magic);
+			const uint32_t k = i - blk * g.cap;
+			const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+			dst[v0 + i] = S(value_decode<E, VC>(u, origin));
+		}
+		__syncthreads();
+	}
+}
+
+// ---- bitpfr exception lists ---------------------------------------------------------
+//
+// A tile is 1024 consecutive values handled by one 256-thread workgroup, four
+// consecutive values per thread.
+
+constexpr int XT_THREADS = 256;
+constexpr int XT_VPT = 4;
+constexpr int XT_TILE = XT_THREADS * XT_VPT;
+constexpr uint64_t XT_NONE = ~uint64_t(0);
+
+template <typename E>
+__device__ __forceinline__ uint32_t exc_flags(const typename E::S *src, size_t n, size_t base,
+					      typename E::C origin, uint32_t nbits,
+					      typename E::C (&hi)[XT_VPT])
+{
+	using C = typename E::C;
+	uint32_t flags = 0;
+#pragma unroll
+	for (int s = 0; s < XT_VPT; s++) {
+		hi[s] = 0;
+		if (base + s < n) {
+			C u = (C(src[base + s]) - origin) & E::MASK;
+			hi[s] = u >> nbits;   // nbits < W for bitpfr (bitpfr.h:65)
+			if (hi[s])
+				flags |= 1u << s;
+		}
+	}
+	return flags;
+}
+
+// Pass 1: per tile, the number of exceptions and the position of the last one.
+template <typename E>
+__global__ __launch_bounds__(XT_THREADS) void k_exc_count(const typename E::S *src, size_t n,
+							    typename E::C origin, uint32_t nbits,
+							    uint32_t *counts, uint64_t *last)
+{
+	__shared__ uint64_t lds[XT_THREADS / WAVE];
+	__shared__ uint64_t lastpos[XT_THREADS / WAVE];
+	const size_t base = size_t(blockIdx.x) * XT_TILE + size_t(threadIdx.x) * XT_VPT;
+	typename E::C hi[XT_VPT];
+	const uint32_t flags = exc_flags<E>(src, n, base, origin, nbits, hi);
+	uint64_t all;
+	wg_scan_u64(uint64_t(__popc(flags)), lds, &all);
+	// highest position with an exception: position + 1, 0 = none
+	uint64_t lp = flags ? base + (31 - __clz(flags)) + 1 : 0;
+	lp = wave_max(lp);
+	if (lane_id() == 0)
+		lastpos[threadIdx.x / WAVE] = lp;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint64_t m = 0;
+		for (int w = 0; w < XT_THREADS / WAVE; w++)
+			m = lastpos[w] > m ? lastpos[w] : m;
+		counts[blockIdx.x] = uint32_t(all);
+		last[blockIdx.x] = m ? m - 1 : XT_NONE;
+	}
+}
+
+// Pass 2: emit (gap, high part) per exception at its global rank.
+template <typename E>
+__global__ __launch_bounds__(XT_THREADS) void k_exc_emit(const typename E::S *src, size_t n,
+							   typename E::C origin, uint32_t nbits,
+							   const uint32_t *counts, const uint64_t *last,
+							   const uint64_t *rank_base, uint64_t *indices,
+							   uint64_t *values, size_t capacity)
+{
+	__shared__ uint64_t lds[XT_THREADS / WAVE];
+	__shared__ uint64_t prev_tile;
+	__shared__ uint64_t wave_last[XT_THREADS / WAVE];
+	const size_t tile = blockIdx.x;
+	if (counts[tile] == 0)
+		return;
+	// the last exception before this tile: nearest earlier tile that has one
+	if (threadIdx.x == 0)
+		prev_tile = XT_NONE;
+	__syncthreads();
+	for (size_t hiT = tile; hiT > 0;) {
+		const size_t lo = hiT > XT_THREADS ? hiT - XT_THREADS : 0;
+		const size_t t = lo + threadIdx.x;
+		uint64_t cand = 0;
+		if (t < hiT && last[t] != XT_NONE)
+			cand = last[t] + 1;
+		// positions grow with the tile index, so the maximum is the nearest
+		cand = wave_max(cand);
+		if (lane_id() == 0)
+			wave_last[threadIdx.x / WAVE] = cand;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint64_t m = 0;
+			for (int w = 0; w < XT_THREADS / WAVE; w++)
+				m = wave_last[w] > m ? wave_last[w] : m;
+			if (m)
+				prev_tile = m - 1;
+		}
+		__syncthreads();
+		if (prev_tile != XT_NONE)
+			break;
+		hiT = lo;
+		__syncthreads();
+	}
+	const uint64_t before = prev_tile;
+
+	const size_t base = tile * XT_TILE + size_t(threadIdx.x) * XT_VPT;
+	typename E::C hi[XT_VPT];
+	const uint32_t flags = exc_flags<E>(src, n, base, origin, nbits, hi);
+	uint64_t all;
+	const uint32_t cnt = uint32_t(__popc(flags));
+	uint64_t rank = rank_base[tile] + wg_scan_u64(cnt, lds, &all) - cnt;
+
+	// last exception position in lower threads of this tile (position + 1, 0 = none)
+	const int lane = lane_id(), wave = threadIdx.x / WAVE;
+	uint64_t lp = flags ? base + (31 - __clz(flags)) + 1 : 0;
+	uint64_t incl = lp;
+#pragma unroll
+	for (int o = 1; o < WAVE; o <<= 1) {
+		uint64_t y = __shfl_up(incl, o, WAVE);
+		if (lane >= o)
+			incl = y > incl ? y : incl;
+	}
+	if (lane == WAVE - 1)
+		wave_last[wave] = incl;
+	__syncthreads();
+	uint64_t prevp = __shfl_up(incl, 1, WAVE);
+	if (lane == 0)
+		prevp = 0;
+	for (int w = 0; w < wave; w++)
+		prevp = wave_last[w] > prevp ? wave_last[w] : prevp;
+	// next expected position (offset.h:55-60): previous + 1, or 0 at the start
+	uint64_t next = prevp ? prevp : (before == XT_NONE ? 0 : before + 1);
+#pragma unroll
+	for (int s = 0; s < XT_VPT; s++) {
+		if (flags & (1u << s)) {
+			const uint64_t pos = base + s;
+			if (rank < capacity) {
+				indices[rank] = pos - next;
+				values[rank] = uint64_t(hi[s]);
+			}
+			next = pos + 1;
+			rank++;
+		}
+	}
+}
+
+// Patch pass of decode, bitpfr.h:114-124: tile t of 2048 exceptions.
+template <typename E>
+__global__ __launch_bounds__(SCAN_THREADS) void k_patch(const uint64_t *indices,
+							  const uint64_t *values, size_t nexc,
+							  const uint64_t *tile_base,
+							  typename E::C origin, uint32_t nbits, size_t n,
+							  typename E::S *dst)
+{
+	using C = typename E::C;
+	using S = typename E::S;
+	__shared__ uint64_t lds[SCAN_THREADS / WAVE];
+	const size_t base = size_t(blockIdx.x) * SCAN_TILE + size_t(threadIdx.x) * SCAN_ITEMS;
+	uint64_t g[SCAN_ITEMS];
+	uint64_t s = 0;
+#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; i++) {
+		g[i] = base + i < nexc ? indices[base + i] + 1 : 0;
+		s += g[i];
+	}
+	uint64_t all;
+	uint64_t run = tile_base[blockIdx.x] + wg_scan_u64(s, lds, &all) - s;
+#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; i++) {
+		if (base + i < nexc) {
+			const uint64_t pos = run + g[i] - 1;
+			if (pos < n) {
+				C u = (C(dst[pos]) - origin) & E::MASK;
+				u |= C(values[base + i]) << nbits;
+				dst[pos] = S((u + origin) & E::MASK);
+			}
+		}
+		run += g[i];
+	}
+}
+
+__global__ void k_store_u64(uint64_t *dst, const uint64_t *src)
+{
+	*dst = *src;
+}
+
+static unsigned pack_grid(size_t ntiles)
+{
+	const size_t cap = 256 * 8;
+	return unsigned(ntiles < cap ? (ntiles ? ntiles : 1) : cap);
+}
+
+template <int VC>
+static int do_pack(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits, void *dst,
+		   void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	const unsigned W = 8u << (dtype >> 1);
+	if (nbits < 1 || nbits > W)
+		return OROCH_E_NBITS;
+	if (n == 0)
+		return 0;
+	if (!src || !dst || (reinterpret_cast<uintptr_t>(dst) & 7u))
+		return OROCH_E_ARGUMENT;
+	const pack_geom g = make_geom(nbits);
+	const size_t nblk = (n + g.cap - 1) / g.cap;
+	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		hipLaunchKernelGGL((k_pack<E, VC>), dim3(pack_grid(ntiles)), dim3(PK_THREADS), 0, st,
+				   static_cast<const typename E::S *>(src), n, nblk, g,
+				   typename E::C(origin & uint64_t(E::MASK)), static_cast<uint64_t *>(dst));
+		return int(hipGetLastError());
+	});
+}
+
+template <int VC>
+static int do_unpack(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits,
+		     void *dst, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	const unsigned W = 8u << (dtype >> 1);
+	if (nbits < 1 || nbits > W)
+		return OROCH_E_NBITS;
+	if (n == 0)
+		return 0;
+	if (!src || !dst || (reinterpret_cast<uintptr_t>(src) & 15u))
+		return OROCH_E_ARGUMENT;
+	const pack_geom g = make_geom(nbits);
+	const size_t nblk = (n + g.cap - 1) / g.cap;
+	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		hipLaunchKernelGGL((k_unpack<E, VC>), dim3(pack_grid(ntiles)), dim3(PK_THREADS), 0, st,
+				   static_cast<const uint4 *>(src), n, nblk, g,
+				   typename E::C(origin & uint64_t(E::MASK)),
+				   static_cast<typename E::S *>(dst));
+		return int(hipGetLastError());
+	});
+}
+
+struct pfr_ws
+{
+	uint32_t *counts;
+	uint64_t *last;
+	uint64_t *rank_base;  // ntiles + 1
+	uint64_t *tile_sums;
+	uint64_t *total;
+	size_t bytes;
+};
+
+static size_t up256(size_t x)
+{
+	return (x + 255) / 256 * 256;
+}
+
+static pfr_ws carve_pfr(void *ws, size_t n)
+{
+	const size_t ntiles = (n + XT_TILE - 1) / XT_TILE;
+	// the decoder scans up to n exceptions in tiles of SCAN_TILE
+	const size_t stiles = scan_tiles(n > ntiles ? n : ntiles) + 1;
+	pfr_ws w;
+	char *p = static_cast<char *>(ws);
+	size_t off = 0;
+	w.counts = reinterpret_cast<uint32_t *>(p + off);
+	off = up256(off + (ntiles + 1) * sizeof(uint32_t));
+	w.last = reinterpret_cast<uint64_t *>(p + off);
+	off = up256(off + (ntiles + 1) * sizeof(uint64_t));
+	w.rank_base = reinterpret_cast<uint64_t *>(p + off);
+	off = up256(off + (ntiles + 2) * sizeof(uint64_t));
+	w.tile_sums = reinterpret_cast<uint64_t *>(p + off);
+	off = up256(off + (stiles + 1) * sizeof(uint64_t));
+	w.total = reinterpret_cast<uint64_t *>(p + off);
+	off = up256(off + 256);
+	w.bytes = off;
+	return w;
+}
+
+} // namespace oroch_hip
+
+using namespace oroch_hip;
+
+extern "C" size_t oroch_bitpck_capacity(unsigned nbits)
+{
+	return nbits ? 128u / nbits : 0;
+}
+
+extern "C" size_t oroch_bitpck_space(size_t nvalues, unsigned nbits)
+{
+	if (!nbits || !nvalues)
+		return 0;
+	const size_t c = 128u / nbits;
+	return 16 * ((nvalues + c - 1) / c);
+}
+
+extern "C" int oroch_bitpck_encode(int dtype, const void *src, size_t n, unsigned nbits, void *dst,
+				   void *stream)
+{
+	return do_pack<VC_ZIGZAG>(dtype, src, n, 0, nbits, dst, stream);
+}
+
+extern "C" int oroch_bitpck_decode(int dtype, const void *src, size_t n, unsigned nbits, void *dst,
+				   void *stream)
+{
+	return do_unpack<VC_ZIGZAG>(dtype, src, n, 0, nbits, dst, stream);
+}
+
+extern "C" int oroch_bitfor_encode(int dtype, const void *src, size_t n, uint64_t origin,
+				   unsigned nbits, void *dst, void *stream)
+{
+	return do_pack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
+}
+
+extern "C" int oroch_bitfor_decode(int dtype, const void *src, size_t n, uint64_t origin,
+				   unsigned nbits, void *dst, void *stream)
+{
+	return do_unpack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
+}
+
+extern "C" size_t oroch_bitpfr_workspace(size_t n)
+{
+	return carve_pfr(nullptr, n).bytes;
+}
+
+extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_t origin,
+				   unsigned nbits, void *dst, uint64_t *indices, uint64_t *values,
+				   size_t exc_capacity, uint64_t *nexc, void *workspace,
+				   size_t workspace_bytes, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	const unsigned W = 8u << (dtype >> 1);
+	if (nbits < 1 || nbits >= W)
+		return OROCH_E_NBITS; // bitpfr.h:65: the mask is (1 << nbits) - 1, nbits < bits(T)
+	if (!nexc || !workspace || (exc_capacity && (!indices || !values)))
+		return OROCH_E_ARGUMENT;
+	if (workspace_bytes < oroch_bitpfr_workspace(n))
+		return OROCH_E_CAPACITY;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (n == 0)
+		return int(hipMemsetAsync(nexc, 0, sizeof(uint64_t), st));
+	int rc = do_pack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
+	if (rc)
+		return rc;
+	pfr_ws w = carve_pfr(workspace, n);
+	const size_t ntiles = (n + XT_TILE - 1) / XT_TILE;
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		using C = typename E::C;
+		const typename E::S *s = static_cast<const typename E::S *>(src);
+		const C org = C(origin & uint64_t(E::MASK));
+		hipLaunchKernelGGL(k_exc_count<E>, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, s, n, org,
+				   nbits, w.counts, w.last);
+		int r = launch_scan<uint32_t, 0>(w.counts, ntiles, w.tile_sums, w.total, w.rank_base, st);
+		if (r)
+			return r;
+		hipLaunchKernelGGL(k_exc_emit<E>, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, s, n, org,
+				   nbits, w.counts, w.last, w.rank_base, indices, values, exc_capacity);
+		hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, st, nexc, w.rank_base + ntiles);
+		return int(hipGetLastError());
+	});
+}
+
+extern "C" int oroch_bitpfr_decode(int dtype, const void *src, size_t n, uint64_t origin,
+				   unsigned nbits, const uint64_t *indices, const uint64_t *values,
+				   size_t nexc, void *dst, void *workspace, size_t workspace_bytes,
+				   void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	const unsigned W = 8u << (dtype >> 1);
+	if (nbits < 1 || nbits >= W)
+		return OROCH_E_NBITS;
+	if (nexc > n || (nexc && (!indices || !values || !workspace)))
+		return OROCH_E_ARGUMENT;
+	if (nexc && workspace_bytes < oroch_bitpfr_workspace(n))
+		return OROCH_E_CAPACITY;
+	int rc = do_unpack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
+	if (rc || nexc == 0)
+		return rc;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	pfr_ws w = carve_pfr(workspace, n);
+	const size_t ntiles = scan_tiles(nexc);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		using C = typename E::C;
+		hipLaunchKernelGGL((k_tile_sums<uint64_t, 1>), dim3(unsigned(ntiles)), dim3(SCAN_THREADS), 0,
+				   st, indices, nexc, w.tile_sums);
+		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, w.tile_sums, ntiles,
+				   w.total);
+		hipLaunchKernelGGL(k_patch<E>, dim3(unsigned(ntiles)), dim3(SCAN_THREADS), 0, st, indices,
+				   values, nexc, w.tile_sums, C(origin & uint64_t(E::MASK)), nbits, n,
+				   static_cast<typename E::S *>(dst));
+		return int(hipGetLastError());
+	});
+}

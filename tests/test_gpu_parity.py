@@ -1,0 +1,250 @@
+"""HIP path (through the C ABI) against the golden fixtures and the CPU oracle.
+
+Byte-exact for every encoded stream, index-exact for exception lists, value
+exact for every decode.
+"""
+import numpy as np
+import pytest
+
+import datagen as dg
+
+pytestmark = pytest.mark.gpu
+
+META_TO_DESC = {"encoding": "encoding", "nbits": "nbits", "origin": "origin",
+                "dataspace": "dataspace", "metaspace": "metaspace", "noutliers": "noutliers",
+                "index_encoding": "index_encoding", "index_nbits": "index_nbits",
+                "value_encoding": "value_encoding", "value_nbits": "value_nbits"}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import oroch_amd
+
+    rc = oroch_amd.lib.oroch_hip_init(0)
+    assert rc == 0, oroch_amd.lib.oroch_hip_strerror(rc)
+    return oroch_amd
+
+
+def dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def check_desc(desc_row, meta, fields, ctx):
+    exp = dict(zip(fields, meta))
+    for mf, df in META_TO_DESC.items():
+        got = int(desc_row[df])
+        want = int(exp[mf])
+        if mf in ("index_encoding", "index_nbits", "value_encoding", "value_nbits") and \
+                exp["encoding"] != 6:
+            continue  # only meaningful for bitpfr
+        assert got == want, (mf, got, want, ctx)
+
+
+def test_golden_single_blocks(hip, golden):
+    z, cases, fields = golden
+    count = 0
+    for i, c in enumerate(cases):
+        if c["kind"] != "group":
+            continue
+        a = z["c%d_in" % i].view(dg.DTYPES[c["dtype"]])
+        x = dev(a)
+        exp = z["c%d_out" % i]
+        if a.size == 0:
+            stream, offs = hip.group_encode(x)
+            assert stream.numel() == 0 and int(offs[0]) == 0
+            continue
+        d = hip.group_select(x)
+        assert d.size == 1
+        check_desc(d[0], c["meta"], fields, (i, c))
+        stream, offs = hip.group_encode(x)
+        got = host(stream)
+        assert int(offs[1]) == got.size and got.size == (exp.size + 15) // 16 * 16, (i, c)
+        assert np.array_equal(got[:exp.size], exp), (i, c)
+        assert not got[exp.size:].any(), (i, c)
+        back = host(hip.group_decode(stream, offs, a.size, a.dtype))
+        assert np.array_equal(back, a), (i, c)
+        count += 1
+    assert count > 800
+
+
+def test_golden_block_streams(hip, golden):
+    z, cases, _ = golden
+    seen = 0
+    for i, c in enumerate(cases):
+        if c["kind"] != "blocks":
+            continue
+        a = z["c%d_in" % i].view(dg.DTYPES[c["dtype"]])
+        stream, offs = hip.group_encode(dev(a))
+        assert np.array_equal(host(offs).astype(np.uint64), z["c%d_offs" % i]), c
+        assert np.array_equal(host(stream), z["c%d_out" % i]), c
+        assert np.array_equal(host(hip.group_decode(stream, offs, a.size, a.dtype)), a), c
+        seen += 1
+    assert seen == 5
+
+
+def test_golden_whole_sequence(hip, golden):
+    z, cases, _ = golden
+    seen = set()
+    for i, c in enumerate(cases):
+        k = c["kind"]
+        if k not in ("bitpck", "bitfor", "bitpfr"):
+            continue
+        seen.add(k)
+        dt = np.dtype(dg.DTYPES[c["dtype"]])
+        a = z["c%d_in" % i].view(dt)
+        exp = z["c%d_out" % i]
+        x = dev(a)
+        W = dt.itemsize * 8
+        if k == "bitpck":
+            got = hip.bitpck_encode(x, c["nbits"])
+            assert np.array_equal(host(got), exp), c
+            back = host(hip.bitpck_decode(got, a.size, c["nbits"], dt))
+            if c["nbits"] >= W:
+                assert np.array_equal(back, a), c
+        elif k == "bitfor":
+            got = hip.bitfor_encode(x, c["origin"], c["nbits"])
+            assert np.array_equal(host(got), exp), c
+        else:
+            got, idx, val, nexc = hip.bitpfr_encode(x, c["origin"], c["nbits"])
+            assert np.array_equal(host(got), exp), c
+            assert nexc == z["c%d_idx" % i].size, c
+            assert np.array_equal(host(idx).astype(np.uint64), z["c%d_idx" % i]), c
+            assert np.array_equal(host(val).astype(np.uint64), z["c%d_val" % i]), c
+            back = host(hip.bitpfr_decode(got, a.size, c["origin"], c["nbits"], idx, val, dt))
+            assert np.array_equal(back, a), c
+    assert seen == {"bitpck", "bitfor", "bitpfr"}
+
+
+@pytest.mark.parametrize("dt", dg.DTYPES)
+def test_fuzz_blocks_against_oracle(hip, oracle, dt):
+    rng = np.random.default_rng(1000 + dg.DTYPES.index(dt))
+    nblocks = 3000
+    a = np.concatenate([dg.fuzz_block(rng, dt, 256) for _ in range(nblocks)] +
+                       [dg.fuzz_block(rng, dt, int(rng.integers(1, 256)))])
+    exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+    x = dev(a)
+    stream, offs = hip.group_encode(x)
+    got_offs = host(offs).astype(np.uint64)
+    bad = np.nonzero(got_offs != exp_offs)[0]
+    if bad.size:
+        b = int(bad[0]) - 1
+        blk = a[b * 256:(b + 1) * 256]
+        d = hip.group_select(dev(blk))[0]
+        raise AssertionError("block %d size differs: hip %s oracle %s" %
+                             (b, d, oracle.select(blk)))
+    got = host(stream)
+    if not np.array_equal(got, exp):
+        pos = int(np.nonzero(got != exp)[0][0])
+        b = int(np.searchsorted(exp_offs, pos, side="right")) - 1
+        raise AssertionError("stream differs at byte %d (block %d, +%d): %s" %
+                             (pos, b, pos - int(exp_offs[b]), oracle.select(a[b * 256:(b + 1) * 256])))
+    # all seven encodings must have been exercised (8-bit types cannot reach varints)
+    encs = set(int(e) for e in hip.group_select(x)["encoding"])
+    assert encs >= ({0, 1, 4, 5, 6} if np.dtype(dt).itemsize == 1 else set(range(7))), encs
+    back = host(hip.group_decode(stream, offs, a.size, dt))
+    assert np.array_equal(back, a)
+
+
+@pytest.mark.parametrize("dt", [np.uint32, np.int32, np.int64, np.uint8, np.int16])
+def test_whole_sequence_against_oracle(hip, oracle, dt):
+    dt = np.dtype(dt)
+    W = dt.itemsize * 8
+    n = 100003
+    for nbits in sorted({1, 2, 3, 5, 7, 10, 13, W // 2, W - 1, W}):
+        a = dg.uniform_bits(n, dt, nbits, W)
+        x = dev(a)
+        got = hip.bitpck_encode(x, nbits)
+        assert np.array_equal(host(got), oracle.bitpck_encode(a, nbits)), nbits
+        assert np.array_equal(host(hip.bitpck_decode(got, n, nbits, dt)),
+                              oracle.bitpck_decode(host(got), n, nbits, dt)), nbits
+        origin = int(a.min())
+        got = hip.bitfor_encode(x, origin, nbits)
+        assert np.array_equal(host(got), oracle.bitfor_encode(a, origin, nbits)), nbits
+        assert np.array_equal(host(hip.bitfor_decode(got, n, origin, nbits, dt)),
+                              oracle.bitfor_decode(host(got), n, origin, nbits, dt)), nbits
+    for nbits, permille in ((1, 500), (4, 10), (W // 2, 1), (W - 1, 3)):
+        a = dg.outlier_mix(n, dt, 9, body_bits=nbits, out_bits=W, permille=permille, shift=-5)
+        origin = int(a.min())
+        x = dev(a)
+        got, idx, val, nexc = hip.bitpfr_encode(x, origin, nbits)
+        eo, ei, ev = oracle.bitpfr_encode(a, origin, nbits)
+        assert nexc == ei.size, nbits
+        assert np.array_equal(host(got), eo), nbits
+        assert np.array_equal(host(idx).astype(np.uint64), ei), nbits
+        assert np.array_equal(host(val).astype(np.uint64), ev), nbits
+        back = host(hip.bitpfr_decode(got, n, origin, nbits, idx, val, dt))
+        assert np.array_equal(back, a), nbits
+
+
+def test_sparse_exceptions_far_apart(hip, oracle):
+    # exceptions thousands of tiles apart: the look-back for the previous one
+    n = 3_000_000
+    a = np.zeros(n, np.uint32)
+    for p in (5, 1_234_567, 1_234_568, 2_999_999):
+        a[p] = 1 << 20
+    got, idx, val, nexc = hip.bitpfr_encode(dev(a), 0, 3)
+    eo, ei, ev = oracle.bitpfr_encode(a, 0, 3)
+    assert nexc == 4 and np.array_equal(host(idx).astype(np.uint64), ei)
+    assert np.array_equal(host(val).astype(np.uint64), ev)
+    assert np.array_equal(host(hip.bitpfr_decode(got, n, 0, 3, idx, val, np.uint32)), a)
+
+
+def test_headline_distribution_round_trip(hip, oracle):
+    # the bench workload at a size the oracle still checks byte for byte
+    n = 256 * 4096
+    a = dg.outlier_mix(n, np.int32, seed=3, shift=-200)
+    x = dev(a)
+    stream, offs = hip.group_encode(x)
+    exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+    assert np.array_equal(host(offs).astype(np.uint64), exp_offs)
+    assert np.array_equal(host(stream), exp)
+    assert np.array_equal(host(hip.group_decode(stream, offs, n, np.int32)), a)
+    d = hip.group_select(x)
+    assert (d["encoding"] == 6).mean() > 0.8
+
+
+def test_large_round_trip_properties(hip):
+    # 2^27 values: round trip, offsets are the running sum of block sizes,
+    # encoding is deterministic
+    import torch
+
+    n = 1 << 27
+    a = dg.outlier_mix(n, np.int32, seed=3, shift=-200)
+    x = dev(a)
+    s1, o1 = hip.group_encode(x)
+    s2, o2 = hip.group_encode(x)
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
+    d = hip.group_select(x)
+    sizes = d["size"].astype(np.uint64)
+    assert np.array_equal(host(o1).astype(np.uint64)[1:], np.cumsum(sizes))
+    back = hip.group_decode(s1, o1, n, np.int32)
+    assert torch.equal(back, x)
+
+
+def test_host_entry_points(hip, oracle):
+    a = dg.outlier_mix(70001, np.uint64, seed=6, body_bits=20, out_bits=50, shift=1 << 40)
+    stream, offs = hip.group_encode_host(a)
+    exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+    assert np.array_equal(offs, exp_offs) and np.array_equal(stream, exp)
+    assert np.array_equal(hip.group_decode_host(stream, offs, a.size, np.uint64), a)
+
+
+def test_argument_errors(hip):
+    import torch
+
+    x = torch.zeros(16, dtype=torch.int32, device="cuda")
+    with pytest.raises(hip.OrochError):
+        hip.bitpck_encode(x, 0)
+    with pytest.raises(hip.OrochError):
+        hip.bitpck_encode(x, 33)
+    with pytest.raises(hip.OrochError):
+        hip.bitpfr_encode(x, 0, 32)
