@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: device-resident per-block encode + decode of int32 values.
+
+Workload (BASELINE.json north star): 2^30 int32 values per GPU, 10-bit noise
+with 1 % 28-bit outliers shifted by -200, cut into blocks of 256 values; every
+block goes through statistics -> codec selection -> offsets scan -> encode
+(mostly patched frame-of-reference), then the stream is decoded back.  One
+"step" is one encode pass plus one decode pass over the whole array with the
+input already resident in HBM.  value = uncompressed bytes through encode plus
+uncompressed bytes through decode, per second, summed over all GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n L]
+
+For N > 1 launch with torch.distributed.run (one rank per GPU); each rank owns
+a contiguous block range (weak scaling: 2^L values per GPU) and only per-shard
+byte counts are exchanged, after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def gen_outlier_mix_torch(n, seed, device, body_bits=10, out_bits=28, permille=10, shift=-200,
+                          start=0, chunk=1 << 26):
+    """tests/datagen.outlier_mix for int32, generated on the device.
+
+    int64 arithmetic wraps like uint64; logical right shifts are emulated.
+    """
+    import torch
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def s64(c):
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        i = torch.arange(start + lo, start + lo + m, dtype=torch.int64, device=device)
+        z = i + seed + s64(0x9E3779B97F4A7C15)
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        r = z ^ lsr(z, 31)
+        v = r & ((1 << body_bits) - 1)
+        hi = lsr(r, 32)
+        # unsigned (r >> 32) % 1000 on a value below 2^32 is a plain remainder
+        sel = (hi % 1000) < permille
+        big = (lsr(r, 12) | (1 << (out_bits - 1))) & ((1 << out_bits) - 1)
+        v = torch.where(sel, v | big, v) + shift
+        out[lo:lo + m] = v.to(torch.int32)
+    return out
+
+
+def cpu_baseline(log2n, seed):
+    """The reference's own code (oracle/_ref) -- or the C port -- on host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datagen as dg
+    from oracle import pyoracle as po
+
+    n = 1 << log2n
+    a = dg.outlier_mix(n, np.int32, seed=seed, shift=-200)
+    nbytes = a.nbytes
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, share)
+    threads = max(1, min(threads, share))
+    if po.ref is not None:
+        def run(t):
+            best = None
+            for _ in range(2):
+                r = po.ref.bench_blocks(a, 256, t)
+                assert r[4] == 1.0, "reference round trip failed"
+                if best is None or r[:3].sum() < best[:3].sum():
+                    best = r
+            return best
+        one, many = run(1), run(threads)
+        gbs = lambda r: 2 * nbytes / r[:3].sum() / 1e9
+        return {
+            "value": gbs(many), "unit": "GB/s", "cores": threads, "kind": "reference",
+            "value_1thread": gbs(one),
+            "phases_1thread_GBps": {"select": nbytes / one[0] / 1e9, "encode": nbytes / one[1] / 1e9,
+                                    "decode": nbytes / one[2] / 1e9},
+            "sample": "2^%d int32 values of the bench distribution, blocks of 256, select+encode+"
+                      "decode by the reference headers (g++ -O2), best of 2, %d std::threads "
+                      "over disjoint block ranges" % (log2n, threads),
+        }
+    o = po.oracle
+    t0 = time.perf_counter()
+    stream, offs = o.blocks_encode(a, 256, 16)
+    t1 = time.perf_counter()
+    back = o.blocks_decode(stream, offs, n, np.int32, 256)
+    t2 = time.perf_counter()
+    assert np.array_equal(back, a)
+    return {"value": 2 * nbytes / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "2^%d int32 values of the bench distribution through the C restatement "
+                      "(encode %.2fs, decode %.2fs)" % (log2n, t1 - t0, t2 - t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=30, help="log2 of values per GPU")
+    ap.add_argument("--cpu-log2n", type=int, default=25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # convenience: start one rank per GPU as children and pass their exit code on
+        import subprocess
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    import torch.distributed as dist
+
+    import oroch_amd
+    from oroch_amd import sharding
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    rc = oroch_amd.lib.oroch_hip_init(local_rank)
+    if rc != 0:
+        raise SystemExit("oroch_hip_init failed: %s" % oroch_amd.lib.oroch_hip_strerror(rc).decode())
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n = 1 << args.log2n
+    seed = 3
+    # rank r owns values [r*n, (r+1)*n) of the N*n-value array
+    x = gen_outlier_mix_torch(n, seed, device, start=rank * n)
+    enc = oroch_amd.GroupEncoder(np.int32, n, device)
+    back = torch.empty_like(x)
+    code = oroch_amd.dtype_code(np.int32)
+
+    def encode():
+        enc.encode(x)
+
+    def decode():
+        rc = oroch_amd.lib.oroch_group_decode(code, enc.out.data_ptr(), enc.offsets.data_ptr(), n,
+                                              back.data_ptr(), oroch_amd.capi._stream())
+        if rc:
+            raise SystemExit("decode failed: %d" % rc)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        encode()
+        decode()
+    barrier()
+    total = int(enc.offsets[-1].item())
+    if not torch.equal(back, x):
+        raise SystemExit("round trip mismatch on rank %d" % rank)
+
+    oroch_amd.profile_start(16 * (args.steps + 1))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    enc_ms = dec_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev[0].record()
+        encode()
+        ev[1].record()
+        decode()
+        ev[2].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = oroch_amd.profile_stop()
+    elapsed = sharding.max_over_ranks(elapsed, device)
+    # per-phase device time of the last step (events are reused, so only the last survives)
+    enc_ms = ev[0].elapsed_time(ev[1])
+    dec_ms = ev[1].elapsed_time(ev[2])
+
+    counts = sharding.gather_byte_counts(total, device)
+    if rank == 0:
+        raw = n * 4
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * 2 * raw / (elapsed / args.steps) / 1e9
+        kern = {}
+        for name, (ms, cnt) in prof.items():
+            kern[name] = ms / cnt
+        # algorithmic HBM bytes per launch: encode side reads the values once and
+        # writes the stream; decode reads the stream and writes the values
+        algo = {"select": raw, "encode": raw + total, "decode": raw + total, "scan": 0}
+        dominant = max((k for k in kern if k in ("select", "encode", "decode")), key=lambda k: kern[k])
+        achieved = algo[dominant] / (kern[dominant] * 1e-3) / 1e9
+        enc_path_ms = sum(kern.get(k, 0.0) for k in ("select", "scan", "encode"))
+        line = {
+            "metric": "device-resident encode+decode GB/s (uncompressed bytes), per-block bitpfr int32",
+            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "int32 2^%d values per GPU, 10-bit body + 1%% 28-bit outliers, "
+                                   "shift -200, blocks of 256, select+scan+encode then decode"
+                                   % args.log2n,
+                       "values_per_gpu": n, "block_values": 256,
+                       "compressed_bytes_per_gpu": total,
+                       "compressed_over_raw": total / raw, "parallelism": "blocks sharded over %d GPU(s), "
+                       "no data-path collective" % world},
+            "encode_GBps": raw / (enc_ms * 1e-3) / 1e9, "decode_GBps": raw / (dec_ms * 1e-3) / 1e9,
+            "kernel_ms": kern,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": algo[dominant],
+                         "encode_path": {"ms": enc_path_ms, "algorithmic_bytes": raw + total,
+                                         "frac": (raw + total) / (enc_path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "decode_path": {"ms": kern.get("decode", 0.0), "algorithmic_bytes": raw + total,
+                                         "frac": (raw + total) / (kern.get("decode", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "shard_bytes": counts,
+        }
+        if not args.no_cpu_baseline and world >= 1:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

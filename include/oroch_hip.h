@@ -176,6 +176,30 @@ int oroch_group_encode_host(int dtype, const void *src_host, size_t n, void *dst
 int oroch_group_decode_host(int dtype, const void *src_host, const uint64_t *offsets_host,
 			    size_t n, void *dst_host);
 
+/* ---- diagnostics ---------------------------------------------------------------- */
+
+/*
+ * Per-kernel device time, measured with HIP events recorded on the stream each
+ * kernel is launched on.  No counterpart in the reference (its benches use
+ * std::chrono around whole calls, tests/bench/group-bench.cc:27-34); used by
+ * bench.py to price the dominant kernel against the HBM roofline.
+ * oroch_hip_profile_start arms recording for at most max_records launches;
+ * oroch_hip_profile_stop waits for the recorded events, adds up milliseconds
+ * and launch counts per kernel id (arrays of OROCH_K_COUNT) and disarms.
+ */
+enum {
+	OROCH_K_SELECT = 0,  /* statistics + selection per block */
+	OROCH_K_SCAN = 1,    /* the three scan launches together */
+	OROCH_K_ENCODE = 2,  /* block images -> stream */
+	OROCH_K_DECODE = 3,  /* stream -> values */
+	OROCH_K_PACK = 4,    /* whole-sequence pack */
+	OROCH_K_UNPACK = 5,  /* whole-sequence unpack */
+	OROCH_K_EXCEPT = 6,  /* whole-sequence exception list passes */
+	OROCH_K_COUNT = 7,
+};
+int oroch_hip_profile_start(int max_records);
+int oroch_hip_profile_stop(double *ms, unsigned *launches);
+
 #ifdef __cplusplus
 }
 #endif

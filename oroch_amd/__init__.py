@@ -9,6 +9,7 @@ from .capi import (  # noqa: F401
     BLOCK_VALUES,
     DTYPES,
     ENCODING_NAMES,
+    GroupEncoder,
     OrochError,
     bitfor_decode,
     bitfor_encode,
@@ -27,4 +28,6 @@ from .capi import (  # noqa: F401
     group_workspace,
     lib,
     library_path,
+    profile_start,
+    profile_stop,
 )

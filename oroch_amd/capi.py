@@ -32,6 +32,13 @@ def library_path():
 
 
 def _load():
+    # torch bundles its own HIP runtime (same soname as the system one).  The
+    # process must hold exactly one runtime, the one that owns torch's streams
+    # and allocations, so torch is loaded first and this library binds to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise ImportError(
@@ -58,6 +65,8 @@ def _load():
         "oroch_group_decode": (i, [i, vp, vp, sz, vp, vp]),
         "oroch_group_encode_host": (i, [i, vp, sz, vp, sz, vp, vp]),
         "oroch_group_decode_host": (i, [i, vp, vp, sz, vp]),
+        "oroch_hip_profile_start": (i, [i]),
+        "oroch_hip_profile_stop": (i, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -175,6 +184,21 @@ def bitpfr_decode(b, n, origin, nbits, idx, val, dtype):
                                    idx.data_ptr(), val.data_ptr(), idx.numel(), out.data_ptr(),
                                    ws.data_ptr(), wsb, _stream()))
     return out
+
+
+KERNEL_NAMES = ["select", "scan", "encode", "decode", "pack", "unpack", "except"]
+
+
+def profile_start(max_records=4096):
+    _check(lib.oroch_hip_profile_start(max_records))
+
+
+def profile_stop():
+    """{kernel name: (total ms, launches)} for the launches since profile_start."""
+    ms = (C.c_double * len(KERNEL_NAMES))()
+    cnt = (C.c_uint * len(KERNEL_NAMES))()
+    _check(lib.oroch_hip_profile_stop(ms, cnt))
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(KERNEL_NAMES) if cnt[i]}
 
 
 def group_bound(dtype, n):

@@ -2,8 +2,102 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
+#include <vector>
 
-#include "../../include/oroch_hip.h"
+#include "common.hpp"
+
+namespace oroch_hip {
+
+namespace {
+struct record
+{
+	int id;
+	hipEvent_t begin, end;
+};
+std::mutex g_prof_lock;
+bool g_prof_on = false;
+size_t g_prof_max = 0;
+std::vector<record> g_prof;
+} // namespace
+
+void profile_mark(int kernel_id, hipStream_t st, bool begin)
+{
+	if (!g_prof_on)
+		return;
+	std::lock_guard<std::mutex> lock(g_prof_lock);
+	if (!g_prof_on)
+		return;
+	if (begin) {
+		if (g_prof.size() >= g_prof_max)
+			return;
+		record r;
+		r.id = kernel_id;
+		if (hipEventCreate(&r.begin) != hipSuccess)
+			return;
+		if (hipEventCreate(&r.end) != hipSuccess) {
+			(void) hipEventDestroy(r.begin);
+			return;
+		}
+		(void) hipEventRecord(r.begin, st);
+		g_prof.push_back(r);
+	} else {
+		for (size_t i = g_prof.size(); i-- > 0;) {
+			if (g_prof[i].id == kernel_id) {
+				(void) hipEventRecord(g_prof[i].end, st);
+				break;
+			}
+		}
+	}
+}
+
+} // namespace oroch_hip
+
+extern "C" int oroch_hip_profile_start(int max_records)
+{
+	using namespace oroch_hip;
+	std::lock_guard<std::mutex> lock(g_prof_lock);
+	for (auto &r : g_prof) {
+		(void) hipEventDestroy(r.begin);
+		(void) hipEventDestroy(r.end);
+	}
+	g_prof.clear();
+	g_prof_max = max_records > 0 ? size_t(max_records) : 0;
+	g_prof_on = g_prof_max > 0;
+	return 0;
+}
+
+extern "C" int oroch_hip_profile_stop(double *ms, unsigned *launches)
+{
+	using namespace oroch_hip;
+	std::lock_guard<std::mutex> lock(g_prof_lock);
+	g_prof_on = false;
+	int rc = 0;
+	for (int k = 0; k < OROCH_K_COUNT; k++) {
+		if (ms)
+			ms[k] = 0;
+		if (launches)
+			launches[k] = 0;
+	}
+	for (auto &r : g_prof) {
+		float t = 0;
+		hipError_t e = hipEventSynchronize(r.end);
+		if (e == hipSuccess)
+			e = hipEventElapsedTime(&t, r.begin, r.end);
+		if (e != hipSuccess)
+			rc = int(e);
+		else if (r.id >= 0 && r.id < OROCH_K_COUNT) {
+			if (ms)
+				ms[r.id] += t;
+			if (launches)
+				launches[r.id] += 1;
+		}
+		(void) hipEventDestroy(r.begin);
+		(void) hipEventDestroy(r.end);
+	}
+	g_prof.clear();
+	return rc;
+}
 
 extern "C" int oroch_hip_init(int device)
 {

@@ -78,6 +78,23 @@ constexpr width_table make_width_table()
 	return t;
 }
 
+// Records a HIP event pair around the launches issued while it is alive, when
+// profiling is armed (oroch_hip_profile_start); otherwise does nothing.
+void profile_mark(int kernel_id, hipStream_t st, bool begin);
+struct profile_scope
+{
+	int id;
+	hipStream_t st;
+	profile_scope(int kernel_id, hipStream_t s) : id(kernel_id), st(s)
+	{
+		profile_mark(id, st, true);
+	}
+	~profile_scope()
+	{
+		profile_mark(id, st, false);
+	}
+};
+
 #ifdef __HIPCC__
 
 __constant__ const width_table g_width = make_width_table();

@@ -886,6 +886,7 @@ extern "C" int oroch_group_select(int dtype, const void *src, size_t n, oroch_bl
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+		profile_scope ps(OROCH_K_SELECT, st);
 		hipLaunchKernelGGL(k_select<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const typename E::S *>(src), n, nb, desc,
 				   static_cast<uint32_t *>(nullptr));
@@ -922,14 +923,22 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 	rc = dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
-		hipLaunchKernelGGL(k_select<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
-				   static_cast<const typename E::S *>(src), n, nb, w.desc, w.sizes);
-		int r = int(hipGetLastError());
+		int r;
+		{
+			profile_scope ps(OROCH_K_SELECT, st);
+			hipLaunchKernelGGL(k_select<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
+					   static_cast<const typename E::S *>(src), n, nb, w.desc, w.sizes);
+			r = int(hipGetLastError());
+		}
 		if (r)
 			return r;
-		r = launch_scan<uint32_t, 0>(w.sizes, nb, w.tile_sums, w.total, offsets, st);
+		{
+			profile_scope ps(OROCH_K_SCAN, st);
+			r = launch_scan<uint32_t, 0>(w.sizes, nb, w.tile_sums, w.total, offsets, st);
+		}
 		if (r)
 			return r;
+		profile_scope ps(OROCH_K_ENCODE, st);
 		hipLaunchKernelGGL(k_encode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
 				   static_cast<uint8_t *>(dst));
@@ -961,6 +970,7 @@ extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *of
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+		profile_scope ps(OROCH_K_DECODE, st);
 		hipLaunchKernelGGL(k_decode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const uint8_t *>(src), offsets, n, nb,
 				   static_cast<typename E::S *>(dst));

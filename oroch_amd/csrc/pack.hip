@@ -330,6 +330,7 @@ static int do_pack(int dtype, const void *src, size_t n, uint64_t origin, unsign
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
+		profile_scope ps(OROCH_K_PACK, st);
 		hipLaunchKernelGGL((k_pack<E, VC>), dim3(pack_grid(ntiles)), dim3(PK_THREADS), 0, st,
 				   static_cast<const typename E::S *>(src), n, nblk, g,
 				   typename E::C(origin & uint64_t(E::MASK)), static_cast<uint64_t *>(dst));
@@ -356,6 +357,7 @@ static int do_unpack(int dtype, const void *src, size_t n, uint64_t origin, unsi
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
+		profile_scope ps(OROCH_K_UNPACK, st);
 		hipLaunchKernelGGL((k_unpack<E, VC>), dim3(pack_grid(ntiles)), dim3(PK_THREADS), 0, st,
 				   static_cast<const uint4 *>(src), n, nblk, g,
 				   typename E::C(origin & uint64_t(E::MASK)),
@@ -474,6 +476,7 @@ extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_
 		using C = typename E::C;
 		const typename E::S *s = static_cast<const typename E::S *>(src);
 		const C org = C(origin & uint64_t(E::MASK));
+		profile_scope ps(OROCH_K_EXCEPT, st);
 		hipLaunchKernelGGL(k_exc_count<E>, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, s, n, org,
 				   nbits, w.counts, w.last);
 		int r = launch_scan<uint32_t, 0>(w.counts, ntiles, w.tile_sums, w.total, w.rank_base, st);
@@ -509,6 +512,7 @@ extern "C" int oroch_bitpfr_decode(int dtype, const void *src, size_t n, uint64_
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		using C = typename E::C;
+		profile_scope ps(OROCH_K_EXCEPT, st);
 		hipLaunchKernelGGL((k_tile_sums<uint64_t, 1>), dim3(unsigned(ntiles)), dim3(SCAN_THREADS), 0,
 				   st, indices, nexc, w.tile_sums);
 		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, w.tile_sums, ntiles,

@@ -159,7 +159,7 @@ def test_whole_sequence_against_oracle(hip, oracle, dt):
     dt = np.dtype(dt)
     W = dt.itemsize * 8
     n = 100003
-    for nbits in sorted({1, 2, 3, 5, 7, 10, 13, W // 2, W - 1, W}):
+    for nbits in sorted(b for b in {1, 2, 3, 5, 7, 10, 13, W // 2, W - 1, W} if b <= W):
         a = dg.uniform_bits(n, dt, nbits, W)
         x = dev(a)
         got = hip.bitpck_encode(x, nbits)
