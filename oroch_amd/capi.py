@@ -28,7 +28,8 @@ class OrochError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "liboroch_hip.so")
+    # OROCH_HIP_LIBRARY lets an experiment load another build of the same ABI
+    return os.environ.get("OROCH_HIP_LIBRARY") or os.path.join(HERE, "liboroch_hip.so")
 
 
 def _load():

@@ -169,56 +169,95 @@ __device__ __forceinline__ int uniform(int x)
 	return __builtin_amdgcn_readfirstlane(x);
 }
 
+// Cross-lane moves by DPP (data-parallel primitives): a VALU operand modifier,
+// a few cycles of latency against ~100 for a round trip through the LDS
+// crossbar (ds_bpermute).  CTRL: 0xb1 / 0x4e quad swaps, 0x11n row_shr:n,
+// 0x12n row_ror:n, 0x142 row_bcast:15, 0x143 row_bcast:31 (rows are 16 lanes).
+// Lanes without a source (or masked out by RM, one bit per row) get `old`.
+template <int CTRL, int RM = 0xf>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t x)
+{
+	return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(x), CTRL, RM, 0xf, false));
+}
+template <int CTRL, int RM = 0xf>
+__device__ __forceinline__ int dpp_mov(int old, int x)
+{
+	return __builtin_amdgcn_update_dpp(old, x, CTRL, RM, 0xf, false);
+}
+template <int CTRL, int RM = 0xf>
+__device__ __forceinline__ uint64_t dpp_mov(uint64_t old, uint64_t x)
+{
+	uint32_t lo = dpp_mov<CTRL, RM>(uint32_t(old), uint32_t(x));
+	uint32_t hi = dpp_mov<CTRL, RM>(uint32_t(old >> 32), uint32_t(x >> 32));
+	return (uint64_t(hi) << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t read_lane(uint32_t x, int l)
+{
+	return uint32_t(__builtin_amdgcn_readlane(int(x), l));
+}
+__device__ __forceinline__ int read_lane(int x, int l)
+{
+	return __builtin_amdgcn_readlane(x, l);
+}
+__device__ __forceinline__ uint64_t read_lane(uint64_t x, int l)
+{
+	return (uint64_t(read_lane(uint32_t(x >> 32), l)) << 32) | read_lane(uint32_t(x), l);
+}
+
+// Full-wave reduction; `ident` is the operation's identity.  The result is
+// wave-uniform (read from lane 63).
+template <typename V, typename Op>
+__device__ __forceinline__ V wave_reduce(V x, V ident, Op op)
+{
+	x = op(x, dpp_mov<0xb1>(ident, x));
+	x = op(x, dpp_mov<0x4e>(ident, x));
+	x = op(x, dpp_mov<0x124>(ident, x));
+	x = op(x, dpp_mov<0x128>(ident, x));
+	x = op(x, dpp_mov<0x142, 0xa>(ident, x));
+	x = op(x, dpp_mov<0x143, 0xc>(ident, x));
+	return read_lane(x, WAVE - 1);
+}
+// Inclusive prefix over lanes 0..lane.
+template <typename V, typename Op>
+__device__ __forceinline__ V wave_scan(V x, V ident, Op op)
+{
+	x = op(x, dpp_mov<0x111>(ident, x));
+	x = op(x, dpp_mov<0x112>(ident, x));
+	x = op(x, dpp_mov<0x114>(ident, x));
+	x = op(x, dpp_mov<0x118>(ident, x));
+	x = op(x, dpp_mov<0x142, 0xa>(ident, x));
+	x = op(x, dpp_mov<0x143, 0xc>(ident, x));
+	return x;
+}
+
 template <typename V>
 __device__ __forceinline__ V wave_min(V x)
 {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		V y = __shfl_xor(x, o, WAVE);
-		x = y < x ? y : x;
-	}
-	return uniform(x);
+	return wave_reduce(x, V(~V(0)), [](V a, V b) { return a < b ? a : b; });
 }
 template <typename V>
 __device__ __forceinline__ V wave_max(V x)
 {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		V y = __shfl_xor(x, o, WAVE);
-		x = y > x ? y : x;
-	}
-	return uniform(x);
+	return wave_reduce(x, V(0), [](V a, V b) { return a > b ? a : b; });
 }
 template <typename V>
 __device__ __forceinline__ V wave_sum(V x)
 {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		x += __shfl_xor(x, o, WAVE);
-	return uniform(x);
+	return wave_reduce(x, V(0), [](V a, V b) { return V(a + b); });
 }
 
 // Inclusive prefix sum over lanes 0..lane.
 __device__ __forceinline__ uint32_t wave_scan_sum(uint32_t x, int lane)
 {
-#pragma unroll
-	for (int o = 1; o < WAVE; o <<= 1) {
-		uint32_t y = __shfl_up(x, o, WAVE);
-		if (lane >= o)
-			x += y;
-	}
-	return x;
+	(void) lane;
+	return wave_scan(x, 0u, [](uint32_t a, uint32_t b) { return a + b; });
 }
-// Inclusive prefix maximum over lanes 0..lane.
+// Inclusive prefix maximum over lanes 0..lane; values are >= -1.
 __device__ __forceinline__ int wave_scan_max(int x, int lane)
 {
-#pragma unroll
-	for (int o = 1; o < WAVE; o <<= 1) {
-		int y = __shfl_up(x, o, WAVE);
-		if (lane >= o)
-			x = y > x ? y : x;
-	}
-	return x;
+	(void) lane;
+	return wave_scan(x, -1, [](int a, int b) { return a > b ? a : b; });
 }
 // Value of lane + o, or 0 past the last lane.
 __device__ __forceinline__ uint32_t shfl_down_zero(uint32_t x, int o, int lane)

@@ -11,6 +11,8 @@
 //   integer_codec.h:386-402, 498-609       encode / decode dispatch, bitpfr lists
 //   integer_group.h:44-76                  [meta][pad to 8][data] framing
 //   bitpck.h:73-201, varint.h:74-115       16-byte block packing, varints
+#include <cstdlib>
+
 #include "common.hpp"
 #include "scan.hpp"
 
@@ -124,7 +126,8 @@ __device__ __forceinline__ int prev_exception(const bool (&f)[VPL], int lane)
 
 // integer_codec.h:234-384 for the block held in v[] (nv valid values).
 // hist: 65 dwords of LDS owned by this wavefront.
-template <typename E>
+// FULL: the block holds all 256 values (every lane's four are valid).
+template <typename E, bool FULL>
 __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, uint32_t *hist,
 			     selection<typename E::C> &sel)
 {
@@ -147,7 +150,7 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	C kmin = ~C(0), kmax = 0;
 #pragma unroll
 	for (int s = 0; s < VPL; s++) {
-		if (lane * VPL + s < nv) {
+		if (FULL || lane * VPL + s < nv) {
 			C k = v[s] ^ E::FLIP;
 			kmin = k < kmin ? k : kmin;
 			kmax = k > kmax ? k : kmax;
@@ -171,7 +174,7 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	uint32_t sums = 0;
 #pragma unroll
 	for (int s = 0; s < VPL; s++) {
-		bool ok = lane * VPL + s < nv;
+		const bool ok = FULL || lane * VPL + s < nv;
 		C d = (v[s] - mn) & E::MASK;
 		ud[s] = bitlen(d);
 		if (ok)
@@ -230,6 +233,9 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	// integer_codec.h:271-272
 	if (nv < 5)
 		return;
+#ifdef OROCH_EXP_NO_PFR
+	return;
+#endif
 
 	// ---- patched frame of reference, integer_codec.h:280-383 ----
 	// histogram of bit lengths into LDS, then lane l looks after width b = l + 1
@@ -239,19 +245,16 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	wave_sync();
 #pragma unroll
 	for (int s = 0; s < VPL; s++)
-		if (lane * VPL + s < nv)
+		if (FULL || lane * VPL + s < nv)
 			atomicAdd(&hist[ud[s]], 1u);
 	wave_sync();
 	const uint32_t b = uint32_t(lane) + 1;
 	const uint32_t hb = hist[b];
 	wave_sync();
 
-	// values longer than b bits: suffix sum of the histogram, shifted by one
-	uint32_t sfx = hb;
-#pragma unroll
-	for (int o = 1; o < WAVE; o <<= 1)
-		sfx += shfl_down_zero(sfx, o, lane);
-	const uint32_t nout = shfl_down_zero(sfx, 1, lane);
+	// values longer than b bits: all non-zero deltas minus those of 1..b bits
+	const uint32_t upto = wave_scan_sum(hb, lane);
+	const uint32_t nout = read_lane(upto, WAVE - 1) - upto;
 	// varint bytes of the high parts: sum over j >= 0 of nout(b + 7j)
 	// (each value of bit length k > b costs ceil((k - b) / 7) bytes, :308-312)
 	uint32_t valvar = nout;
@@ -275,6 +278,9 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	// Replay of the reference's ascending loop.  `best` only shrinks, so a
 	// width failing the gate (:327-335) against the initial value fails later.
 	uint64_t cand = __ballot(active && est < best);
+#ifdef OROCH_EXP_NO_WALK
+	cand = 0;
+#endif
 	while (cand) {
 		const int L = __builtin_ctzll(cand);
 		cand &= cand - 1;
@@ -288,7 +294,7 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 		bool f[VPL];
 #pragma unroll
 		for (int s = 0; s < VPL; s++)
-			f[s] = lane * VPL + s < nv && ud[s] > bL;
+			f[s] = (FULL || lane * VPL + s < nv) && ud[s] > bL;
 		int prev = prev_exception(f, lane);
 		uint32_t gmax = 0, gsum = 0;
 #pragma unroll
@@ -323,7 +329,228 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 			sel.venc = uint32_t(__builtin_amdgcn_readlane(int(venc), L));
 			sel.vnbits = nbmax - bL;
 			sel.ienc = ienc;
-			sel.inbits = indnbits;
+			sel.inbits = ienc == OROCH_BITPCK ? indnbits : 0u;
+			sel.metaspace = 1 + basic_meta + xm;
+			sel.dataspace = required - basic_meta - xm;
+		}
+	}
+}
+
+// ---- selection, full blocks -----------------------------------------------------
+//
+// Same rule as select_block for a block of exactly 256 values, arranged to
+// keep the vector instruction count down:
+//  * both bit-length histograms (of v - min and of zigzag(v)) are built with LDS
+//    atomics; the two varint footprints (integer_codec.h:485-489) and the two
+//    bit-packing widths (:441-452, :465-468) then come from the histograms, one
+//    bin per lane, instead of from per-value arithmetic and a max reduction;
+//  * per-lane constants (bytes of a varint of lane + 1 bits, space of 256 values
+//    at lane + 1 bits) are computed once per kernel;
+//  * the index-gap walk (:338-351) is skipped where its outcome is forced:
+//    with at most one value inside the width every gap is 0 or 1, and with at
+//    most 14 exceptions the varint list (<= 15 bytes) always beats a packed one
+//    (>= 16 bytes), so only "is some gap >= 128" is needed.
+//    In that last case index_nbits is left 0: it is not part of the stream
+//    when the index list is a varint list (integer_codec.h:177-182).
+
+struct lane_consts
+{
+	uint32_t w;       // varint bytes of a value of bit length lane + 1
+	uint32_t pck256;  // bitpck space of 256 values at lane + 1 bits
+};
+
+__device__ __forceinline__ lane_consts make_lane_consts(int lane)
+{
+	lane_consts lc;
+	lc.w = vsp_bits(uint32_t(lane) + 1);
+	lc.pck256 = pck_space(BLOCK, uint32_t(lane) + 1);
+	return lc;
+}
+
+// hq: 65 x 4 dwords of LDS owned by this wavefront (16-byte aligned).
+// wt: {capacity, magic} per width, shared by the workgroup (width_table in LDS).
+// ud[]: bit lengths of the deltas, for the caller.
+template <typename E>
+__device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *hq, const uint2 *wt,
+			    const lane_consts &lc, selection<typename E::C> &sel)
+{
+	using C = typename E::C;
+
+	sel.encoding = OROCH_NORMAL;
+	sel.nbits = 0;
+	sel.metaspace = 1;
+	sel.dataspace = 0;
+	sel.noutliers = 0;
+	sel.ienc = sel.venc = OROCH_NORMAL;
+	sel.inbits = sel.vnbits = 0;
+	sel.origin = 0;
+
+	C kmin = v[0] ^ E::FLIP;
+#pragma unroll
+	for (int s = 1; s < VPL; s++) {
+		const C k = v[s] ^ E::FLIP;
+		kmin = k < kmin ? k : kmin;
+	}
+	const C mn = wave_min(kmin) ^ E::FLIP;
+	const uint32_t vo = vsp(zz<E>(mn));
+
+	// Bin k of the table is four dwords, one per lane & 3, each holding the
+	// delta count in its low half and the zigzag count in its high half: the
+	// copies cut same-address serialisation of the LDS atomics by four.
+	uint32_t ud[VPL];
+	*reinterpret_cast<uint4 *>(&hq[lane * 4]) = make_uint4(0, 0, 0, 0);
+	if (lane == 0)
+		*reinterpret_cast<uint4 *>(&hq[256]) = make_uint4(0, 0, 0, 0);
+	wave_sync();
+	uint32_t *mine = hq + (lane & 3);
+#pragma unroll
+	for (int s = 0; s < VPL; s++) {
+		ud[s] = bitlen(C((v[s] - mn) & E::MASK));
+		atomicAdd(&mine[ud[s] * 4], 1u);
+		atomicAdd(&mine[bitlen(zz<E>(v[s])) * 4], 0x10000u);
+	}
+	wave_sync();
+	const uint4 q = *reinterpret_cast<const uint4 *>(&hq[(lane + 1) * 4]);
+	const uint4 q0 = *reinterpret_cast<const uint4 *>(&hq[0]);
+	wave_sync();
+	const uint32_t qs = q.x + q.y + q.z + q.w, q0s = uniform(q0.x + q0.y + q0.z + q0.w);
+	const uint2 h = make_uint2(qs & 0xffffu, qs >> 16);
+	const uint32_t zero_d = q0s & 0xffffu, zero_z = q0s >> 16;
+
+	// integer_codec.h:255-264
+	if (zero_d == BLOCK) {
+		sel.encoding = OROCH_NAUGHT;
+		sel.origin = mn;
+		sel.metaspace = 1 + vo;
+		return;
+	}
+
+	const uint32_t t = wave_sum(h.x * lc.w + ((h.y * lc.w) << 16));
+	const uint32_t vfs = (t & 0xffffu) + zero_d, vis = (t >> 16) + zero_z;
+	const uint32_t nbmax = 64u - uint32_t(__builtin_clzll(__ballot(h.x != 0)));
+	const uint64_t zbins = __ballot(h.y != 0);
+	const uint32_t nbz = zbins ? 64u - uint32_t(__builtin_clzll(zbins)) : 1u;
+
+	// select_basic, integer_codec.h:422-496
+	uint32_t best = BLOCK * E::BYTES, bmeta0 = 0;
+	{
+		const uint32_t total = read_lane(lc.pck256, int(nbz) - 1) + 1;
+		if (total < best) {
+			best = total;
+			bmeta0 = 1;
+			sel.encoding = OROCH_BITPCK;
+			sel.nbits = nbz;
+		}
+	}
+	{
+		const uint32_t total = read_lane(lc.pck256, int(nbmax) - 1) + 1 + vo;
+		if (total < best) {
+			best = total;
+			bmeta0 = 1 + vo;
+			sel.encoding = OROCH_BITFOR;
+			sel.nbits = nbmax;
+			sel.origin = mn;
+		}
+		if (vis < best) {
+			best = vis;
+			bmeta0 = 0;
+			sel.encoding = OROCH_VARINT;
+			sel.nbits = 0;
+			sel.origin = 0;
+		}
+		if (vfs + vo < best) {
+			best = vfs + vo;
+			bmeta0 = vo;
+			sel.encoding = OROCH_VARFOR;
+			sel.nbits = 0;
+			sel.origin = mn;
+		}
+	}
+	sel.metaspace = 1 + bmeta0;
+	sel.dataspace = best - bmeta0;
+
+	// ---- patched frame of reference, integer_codec.h:280-383; lane l <-> width l + 1
+	const uint32_t b = uint32_t(lane) + 1;
+	const uint32_t upto = wave_scan_sum(h.x, lane);
+	const uint32_t nout = read_lane(upto, WAVE - 1) - upto;
+	uint32_t valvar = nout;
+	valvar += shfl_down_zero(valvar, 7, lane);
+	valvar += shfl_down_zero(valvar, 14, lane);
+	valvar += shfl_down_zero(valvar, 28, lane);
+	valvar += shfl_down_zero(valvar, 56, lane);
+
+	const bool active = b < nbmax && h.x != 0;
+	const uint32_t basic_meta = 1 + vo;
+	const uint32_t xmeta = 2 + (nout < 128u ? 1u : 2u);
+	const uint2 cm = wt[active ? nbmax - b : 1u];
+	const uint32_t valpck = 16u * __umulhi(nout + cm.x - 1u, cm.y);
+	const uint32_t venc = valpck < valvar ? OROCH_BITPCK : OROCH_VARINT;
+	const uint32_t vdata = valpck < valvar ? valpck : valvar;
+	const uint32_t indmin = nout > 128u ? 32u : 16u; // min(pck(nout, 1), 256), nout in 1..255
+	const uint32_t fixed = basic_meta + xmeta + lc.pck256 + vdata;
+	const uint32_t est = fixed + indmin;
+
+	uint64_t cand = __ballot(active && est < best);
+	while (cand) {
+		const int L = __builtin_ctzll(cand);
+		cand &= cand - 1;
+		if (read_lane(est, L) >= best)
+			continue;
+		const uint32_t bL = uint32_t(L) + 1;
+		const uint32_t noutL = read_lane(nout, L);
+		uint32_t indnbits, indvar;
+		if (noutL >= BLOCK - 1) {
+			indnbits = 1;
+			indvar = noutL;
+		} else {
+			// last exception at or before each lane, then the gaps, :338-351
+			bool f[VPL];
+#pragma unroll
+			for (int s = 0; s < VPL; s++)
+				f[s] = ud[s] > bL;
+			int prev = prev_exception(f, lane);
+			if (noutL <= 14) {
+				// only the gap in front of each lane's first exception can be long
+				int first = f[0] ? 0 : f[1] ? 1 : f[2] ? 2 : 3;
+				const bool any = f[0] | f[1] | f[2] | f[3];
+				const bool big = any && lane * VPL + first - prev - 1 >= 128;
+				indnbits = 0;
+				indvar = noutL + (__ballot(big) ? 1u : 0u);
+			} else {
+				uint32_t gmax = 0;
+#pragma unroll
+				for (int s = 0; s < VPL; s++) {
+					const int pos = lane * VPL + s;
+					const uint32_t gap = uint32_t(pos - prev - 1);
+					gmax = f[s] && gap > gmax ? gap : gmax;
+					prev = f[s] ? pos : prev;
+				}
+				gmax = wave_max(gmax);
+				indnbits = bitlen(gmax);
+				indnbits = indnbits ? indnbits : 1u;
+				// 256 positions hold at most one gap of 128 or more
+				indvar = noutL + (gmax >= 128u ? 1u : 0u);
+			}
+		}
+		uint32_t indpck = ~0u;
+		if (indnbits) {
+			const uint2 ci = wt[indnbits];
+			indpck = 16u * __umulhi(noutL + uniform(ci.x) - 1u, uniform(ci.y));
+		}
+		const uint32_t ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
+		const uint32_t idata = indpck < indvar ? indpck : indvar;
+		const uint32_t required = read_lane(fixed, L) + idata;
+		if (required < best) {
+			best = required;
+			const uint32_t xm = read_lane(xmeta, L);
+			sel.encoding = OROCH_BITPFR;
+			sel.origin = mn;
+			sel.nbits = bL;
+			sel.noutliers = noutL;
+			sel.venc = read_lane(venc, L);
+			sel.vnbits = nbmax - bL;
+			sel.ienc = ienc;
+			sel.inbits = ienc == OROCH_BITPCK ? indnbits : 0u;
 			sel.metaspace = 1 + basic_meta + xm;
 			sel.dataspace = required - basic_meta - xm;
 		}
@@ -387,7 +614,7 @@ __device__ __forceinline__ uint32_t put_varint(uint8_t *img, uint32_t pos, uint6
 
 // Builds [meta][pad to 8][data] (integer_group.h:44-60) for the block in v[]
 // into `img` (LDS, 16-byte aligned, zero filled here) and returns its length.
-template <typename E>
+template <typename E, bool FULL>
 __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane,
 				 const selection<typename E::C> &sel, uint32_t *img)
 {
@@ -401,30 +628,48 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 		*reinterpret_cast<uint4 *>(img8 + o) = make_uint4(0, 0, 0, 0);
 	wave_sync();
 
-	// metadata, integer_codec.h:128-151, 177-182, 196-204
-	if (lane == 0) {
-		uint32_t p = 0;
-		img8[p++] = uint8_t(sel.encoding);
+	// metadata, integer_codec.h:128-151, 177-182, 196-204: at most 16 bytes,
+	// assembled in two scalar registers and stored by one lane
+	{
+		uint64_t h[2] = {sel.encoding, 0};
+		uint32_t p = 1;
+		auto put = [&](uint32_t byte) {
+			h[p >> 3] |= uint64_t(byte) << ((p & 7u) * 8u);
+			p++;
+		};
+		auto put_var = [&](uint64_t u) {
+			while (u >= 0x80) {
+				put(uint32_t(u & 0x7f) | 0x80u);
+				u >>= 7;
+			}
+			put(uint32_t(u));
+		};
 		switch (sel.encoding) {
 		case OROCH_NAUGHT:
 		case OROCH_VARFOR:
-			p = put_varint(img8, p, uint64_t(zz<E>(sel.origin)));
+			put_var(uint64_t(zz<E>(sel.origin)));
 			break;
 		case OROCH_BITPFR:
 		case OROCH_BITFOR:
-			p = put_varint(img8, p, uint64_t(zz<E>(sel.origin)));
-			img8[p++] = uint8_t(sel.nbits);
+			put_var(uint64_t(zz<E>(sel.origin)));
+			put(sel.nbits);
 			break;
 		case OROCH_BITPCK:
-			img8[p++] = uint8_t(sel.nbits);
+			put(sel.nbits);
 			break;
 		default:
 			break;
 		}
 		if (sel.encoding == OROCH_BITPFR) {
-			p = put_varint(img8, p, sel.noutliers);
-			img8[p++] = sel.ienc == OROCH_BITPCK ? uint8_t(sel.inbits) : uint8_t(0);
-			img8[p++] = sel.venc == OROCH_BITPCK ? uint8_t(sel.vnbits) : uint8_t(0);
+			put_var(sel.noutliers);
+			put(sel.ienc == OROCH_BITPCK ? sel.inbits : 0u);
+			put(sel.venc == OROCH_BITPCK ? sel.vnbits : 0u);
+		}
+		if (lane == 0) {
+			uint64_t *img64 = reinterpret_cast<uint64_t *>(img);
+			img64[0] = h[0];
+			if (p > 8)
+				img64[1] = h[1];
 		}
 	}
 
@@ -434,7 +679,7 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 		typename E::S *raw = reinterpret_cast<typename E::S *>(img8 + doff);
 #pragma unroll
 		for (int s = 0; s < VPL; s++)
-			if (lane * VPL + s < nv)
+			if (FULL || lane * VPL + s < nv)
 				raw[lane * VPL + s] = typename E::S(v[s]);
 	} else if (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) {
 		// bitpck.h:73-128: value k of a 16-byte block at bit k * nbits
@@ -445,7 +690,7 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 		bool f[VPL];
 #pragma unroll
 		for (int s = 0; s < VPL; s++) {
-			const bool ok = lane * VPL + s < nv;
+			const bool ok = FULL || lane * VPL + s < nv;
 			u[s] = enc == OROCH_BITPCK ? zz<E>(v[s]) : C((v[s] - sel.origin) & E::MASK);
 			f[s] = ok && enc == OROCH_BITPFR && (u[s] & ~low) != 0;
 			if (ok) {
@@ -513,13 +758,13 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 #pragma unroll
 		for (int s = 0; s < VPL; s++) {
 			u[s] = enc == OROCH_VARINT ? zz<E>(v[s]) : C((v[s] - sel.origin) & E::MASK);
-			if (lane * VPL + s < nv)
+			if (FULL || lane * VPL + s < nv)
 				len += vsp(u[s]);
 		}
 		uint32_t at = doff + wave_scan_sum(len, lane) - len;
 #pragma unroll
 		for (int s = 0; s < VPL; s++)
-			if (lane * VPL + s < nv)
+			if (FULL || lane * VPL + s < nv)
 				at = put_varint(img8, at, uint64_t(u[s]));
 	}
 	wave_sync();
@@ -537,27 +782,51 @@ __device__ __forceinline__ void flush_image(const uint32_t *img, uint32_t len, u
 
 // ---- kernels ----------------------------------------------------------------------
 
+// Copies the width table into LDS (dynamic per-lane indexing is cheap there).
+__device__ __forceinline__ void load_width_table(uint2 *wt)
+{
+	for (int i = threadIdx.x; i < 65; i += blockDim.x)
+		wt[i] = make_uint2(g_width.cap[i], g_width.magic[i]);
+	__syncthreads();
+}
+
+// Selection for the block in v[]: the lean path for full blocks, the general
+// one for a short last block.
+template <typename E>
+__device__ __forceinline__ void select_any(const typename E::C (&v)[VPL], int nv, int lane,
+					   uint32_t *hq, const uint2 *wt, const lane_consts &lc,
+					   selection<typename E::C> &sel)
+{
+	if (nv == BLOCK)
+		select_full<E>(v, lane, hq, wt, lc, sel);
+	else
+		select_block<E, false>(v, nv, lane, hq, sel);
+}
+
 template <typename E>
 __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select(const typename E::S *src, size_t n,
 								 size_t nblocks, oroch_block_desc *desc,
 								 uint32_t *sizes)
 {
-	__shared__ uint32_t hist[WAVES_PER_WG][80];
-	const int wave = threadIdx.x / WAVE, lane = lane_id();
-	const size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
-	if (blk >= nblocks)
-		return;
-	const size_t base = blk * BLOCK;
-	const int nv = int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
-	typename E::C v[VPL];
-	load_block<E>(src, base, nv, lane, v);
-	selection<typename E::C> sel;
-	select_block<E>(v, nv, lane, hist[wave], sel);
-	if (lane == 0) {
-		if (desc)
-			put_desc(&desc[blk], sel, nv);
-		if (sizes)
-			sizes[blk] = stream_size(sel);
+	__shared__ __attribute__((aligned(16))) uint32_t hist2[WAVES_PER_WG][264];
+	__shared__ uint2 wt[65];
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	load_width_table(wt);
+	const lane_consts lc = make_lane_consts(lane);
+	for (size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave; blk < nblocks;
+	     blk += size_t(gridDim.x) * WAVES_PER_WG) {
+		const size_t base = blk * BLOCK;
+		const int nv = int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
+		typename E::C v[VPL];
+		load_block<E>(src, base, nv, lane, v);
+		selection<typename E::C> sel;
+		select_any<E>(v, nv, lane, hist2[wave], wt, lc, sel);
+		if (lane == 0) {
+			if (desc)
+				put_desc(&desc[blk], sel, nv);
+			if (sizes)
+				sizes[blk] = stream_size(sel);
+		}
 	}
 }
 
@@ -568,7 +837,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode(const typename E:
 								 const uint64_t *offsets, uint8_t *dst)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
-	const int wave = threadIdx.x / WAVE, lane = lane_id();
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
 	const size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
 	if (blk >= nblocks)
 		return;
@@ -579,8 +848,210 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode(const typename E:
 	selection<typename E::C> sel;
 	get_desc(&desc[blk], sel);
 	const uint64_t off = uniform(offsets[blk]);
-	const uint32_t len = encode_block<E>(v, nv, lane, sel, image[wave]);
+	const uint32_t len = nv == BLOCK ? encode_block<E, true>(v, nv, lane, sel, image[wave])
+					 : encode_block<E, false>(v, nv, lane, sel, image[wave]);
 	flush_image(image[wave], len, dst + off, lane);
+}
+
+// ---- single-pass encode ----------------------------------------------------------------
+//
+// Selection, image building and the offsets scan in ONE launch, so the values
+// are read from HBM once.  A tile is FUSED_WAVES * R consecutive blocks owned by
+// one workgroup: every wavefront selects and builds the images of its R blocks
+// back to back in an LDS arena (that arena already is the wave's piece of the
+// stream), the workgroup publishes its byte count, looks back over the counts
+// of the tiles before it (chained scan with decoupled look-back) and copies
+// the arenas out at the resulting offset.
+//
+// Workgroups are persistent: workgroup g handles tiles g, g + G, g + 2G, ...
+// and a tile only ever waits for lower-numbered tiles.  The grid is sized to
+// what the chip holds at once, so the owner of the lowest unfinished tile is
+// always running and the chain cannot stall.  Every wait is bounded all the
+// same: if one runs out, the abort word is set, nothing more is written and
+// the host falls back to the two-pass path.
+//
+// state[t]: bits 63..62 = 0 nothing yet, 1 = bytes of tile t, 2 = bytes of
+// tiles 0..t; bits 61..0 the byte count.  One naturally aligned 8-byte word
+// written by one write-through store and polled with cache-bypassing loads, so
+// it needs no fence.
+
+constexpr int FUSED_WAVES = 4;
+constexpr uint64_t ST_AGG = uint64_t(1) << 62, ST_PREFIX = uint64_t(2) << 62;
+constexpr uint64_t ST_VALUE = (uint64_t(1) << 62) - 1;
+constexpr uint32_t SPIN_LIMIT = 1u << 18;
+
+template <typename E>
+constexpr int fused_blocks_per_wave()
+{
+	return E::BYTES == 8 ? 2 : 4;
+}
+
+__device__ __forceinline__ void state_store(uint64_t *p, uint64_t v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t state_load(const uint64_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Sum of the byte counts of tiles 0..tile-1, by one wavefront: lane l looks at
+// tile (tile - 1 - l) of the current window of 64; the nearest tile holding a
+// running total ends the walk.  Returns false if a wait ran out.
+__device__ __forceinline__ bool look_back(const uint64_t *state, size_t tile, int lane,
+					  const uint32_t *abort_flag, uint64_t &exclusive)
+{
+	uint64_t sum = 0;
+	long long win = (long long) tile - 1;
+	for (;;) {
+		const long long idx = win - lane;
+		uint64_t w;
+		uint32_t spins = 0;
+		for (;;) {
+			w = idx >= 0 ? state_load(&state[idx]) : ST_PREFIX;
+			if (__ballot((w >> 62) == 0) == 0)
+				break;
+			spins++;
+			if (spins > SPIN_LIMIT)
+				return false;
+			if ((spins & 255u) == 0 &&
+			    __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+				return false;
+			__builtin_amdgcn_s_sleep(2);
+		}
+		const uint64_t have_prefix = __ballot((w >> 62) == 2);
+		const uint32_t bytes = uint32_t(w & ST_VALUE); // a single tile's count fits 32 bits
+		if (have_prefix) {
+			const int k = __builtin_ctzll(have_prefix);
+			sum += wave_sum(lane < k ? bytes : 0u) + (read_lane(w, k) & ST_VALUE);
+			exclusive = sum;
+			return true;
+		}
+		sum += wave_sum(bytes);
+		win -= WAVE;
+	}
+}
+
+template <typename E>
+__global__ __launch_bounds__(WAVE *FUSED_WAVES) void k_encode_fused(
+	const typename E::S *src, size_t n, size_t nblocks, size_t ntiles, uint8_t *dst,
+	uint64_t *offsets, uint64_t *state, uint32_t *abort_flag)
+{
+	constexpr int R = fused_blocks_per_wave<E>();
+	constexpr int IMG = image_bytes<E>() - 16; // longest image, rounded up to 16
+	constexpr int ARENA = R * IMG + 16;
+	__shared__ __attribute__((aligned(16))) uint32_t arena[FUSED_WAVES][ARENA / 4];
+	__shared__ __attribute__((aligned(16))) uint32_t hist2[FUSED_WAVES][264];
+	__shared__ uint2 wt[65];
+	__shared__ uint32_t blkpos[FUSED_WAVES][R];
+	__shared__ uint32_t wave_total[FUSED_WAVES];
+	__shared__ uint64_t tile_base;
+	__shared__ uint32_t aborted;
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	load_width_table(wt);
+	const lane_consts lc = make_lane_consts(lane);
+
+	// The wave's blocks in the order it meets them: tile blockIdx.x + (j / R) *
+	// gridDim.x, block j % R of the wave's share.  Loads run two blocks ahead of
+	// the block being worked on, so that every wave keeps a few KiB in flight
+	// (HBM latency is several thousand cycles under load).
+	auto block_of = [&](size_t j) -> size_t {
+		const size_t tile = blockIdx.x + (j / R) * gridDim.x;
+		return tile < ntiles ? (tile * FUSED_WAVES + wave) * R + j % R : nblocks;
+	};
+	auto count_of = [&](size_t blk) -> int {
+		if (blk >= nblocks)
+			return 0;
+		const size_t base = blk * BLOCK;
+		return int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
+	};
+#ifdef OROCH_EXP_STAGGER
+	// spread the workgroups' phases over one tile time so that the tiles of a
+	// round finish in tile order instead of all at once
+	for (unsigned i = 0, e = unsigned(uint64_t(blockIdx.x) * OROCH_EXP_STAGGER / gridDim.x); i < e; i++)
+		__builtin_amdgcn_s_sleep(10);
+#endif
+	typename E::C v[VPL], v1[VPL], v2[VPL];
+	size_t j = 0;
+	load_block<E>(src, block_of(0) * BLOCK, count_of(block_of(0)), lane, v);
+	load_block<E>(src, block_of(1) * BLOCK, count_of(block_of(1)), lane, v1);
+
+	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const size_t blk0 = (tile * FUSED_WAVES + wave) * R;
+		uint32_t pos = 0;
+#pragma unroll 1
+		for (int r = 0; r < R; r++, j++) {
+			const size_t blk = blk0 + r;
+			if (lane == 0)
+				blkpos[wave][r] = pos;
+			{
+				const size_t ahead = block_of(j + 2);
+				load_block<E>(src, ahead * BLOCK, count_of(ahead), lane, v2);
+			}
+			if (blk < nblocks) {
+				const int nv = count_of(blk);
+				selection<typename E::C> sel;
+				uint32_t len;
+				select_any<E>(v, nv, lane, hist2[wave], wt, lc, sel);
+				if (nv == BLOCK)
+					len = encode_block<E, true>(v, nv, lane, sel, arena[wave] + pos / 4);
+				else
+					len = encode_block<E, false>(v, nv, lane, sel, arena[wave] + pos / 4);
+				pos += (len + 15u) & ~15u;
+			}
+#pragma unroll
+			for (int s = 0; s < VPL; s++) {
+				v[s] = v1[s];
+				v1[s] = v2[s];
+			}
+		}
+		if (lane == 0)
+			wave_total[wave] = pos;
+		__syncthreads();
+		if (wave == 0) {
+			uint32_t tile_bytes = 0;
+#pragma unroll
+			for (int w = 0; w < FUSED_WAVES; w++)
+				tile_bytes += wave_total[w];
+			if (lane == 0)
+				state_store(&state[tile], (tile == 0 ? ST_PREFIX : ST_AGG) | tile_bytes);
+			uint64_t exclusive = 0;
+#ifdef OROCH_EXP_NO_LOOKBACK
+			const bool ok = true;
+#else
+			const bool ok = tile == 0 || look_back(state, tile, lane, abort_flag, exclusive);
+#endif
+			if (lane == 0) {
+				if (ok && tile != 0)
+					state_store(&state[tile], ST_PREFIX | (exclusive + tile_bytes));
+				if (!ok)
+					__hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (ok && tile == ntiles - 1)
+					offsets[nblocks] = exclusive + tile_bytes;
+				tile_base = exclusive;
+				aborted = ok ? 0u : 1u;
+			}
+		}
+		__syncthreads();
+		if (!aborted) {
+			uint64_t base = tile_base;
+			for (int w = 0; w < wave; w++)
+				base += wave_total[w];
+			const uint8_t *a8 = reinterpret_cast<const uint8_t *>(arena[wave]);
+			for (uint32_t o = uint32_t(lane) * 16u; o < pos; o += WAVE * 16u)
+				*reinterpret_cast<uint4 *>(dst + base + o) = *reinterpret_cast<const uint4 *>(a8 + o);
+			if (lane < R && blk0 + lane < nblocks)
+				offsets[blk0 + lane] = base + blkpos[wave][lane];
+		}
+		__syncthreads();
+	}
+}
+
+// offsets[nblocks] = all ones when the single-pass kernel gave up.
+__global__ void k_fused_finish(const uint32_t *abort_flag, uint64_t *offsets, size_t nblocks)
+{
+	if (*abort_flag)
+		offsets[nblocks] = ~uint64_t(0);
 }
 
 // ---- decode -------------------------------------------------------------------------
@@ -664,7 +1135,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *sr
 	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
 	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK];
 	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
-	const int wave = threadIdx.x / WAVE, lane = lane_id();
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
 	const size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
 	if (blk >= nblocks)
 		return;
@@ -829,6 +1300,9 @@ struct group_ws
 	uint32_t *sizes;
 	uint64_t *tile_sums;
 	uint64_t *total;
+	uint32_t *abort_flag;  // 16 bytes, directly in front of state (one memset)
+	uint64_t *state;       // one word per tile of the single-pass kernel
+	size_t state_bytes;    // abort word + state, a multiple of 16
 	size_t bytes;
 };
 
@@ -847,8 +1321,47 @@ static group_ws carve_ws(void *ws, size_t n)
 	off = align_up(off + (ntiles + 1) * sizeof(uint64_t), 256);
 	w.total = reinterpret_cast<uint64_t *>(p + off);
 	off = align_up(off + 256, 256);
+	// the smallest tile is FUSED_WAVES * 2 blocks
+	const size_t max_tiles = (nb + FUSED_WAVES * 2 - 1) / (FUSED_WAVES * 2);
+	w.abort_flag = reinterpret_cast<uint32_t *>(p + off);
+	w.state = reinterpret_cast<uint64_t *>(p + off + 16);
+	w.state_bytes = align_up(16 + max_tiles * sizeof(uint64_t), 16);
+	off = align_up(off + w.state_bytes, 256);
 	w.bytes = off;
 	return w;
+}
+
+// Workgroups of the single-pass kernel the device holds at once.  The occupancy
+// query can read one workgroup per CU high for kernels with many scalar
+// registers, and a grid that is not fully resident would stall the look-back
+// chain, so one workgroup per CU is given up as margin.
+template <typename E>
+static int fused_resident_workgroups()
+{
+	static int cached = 0;
+	if (cached)
+		return cached;
+	int dev = 0, cus = 0, per_cu = 0;
+	if (hipGetDevice(&dev) != hipSuccess ||
+	    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_encode_fused<E>, WAVE * FUSED_WAVES,
+							  0) != hipSuccess)
+		return -1;
+	per_cu = per_cu > 8 ? 8 : per_cu;
+	// the query is exact when vector registers or LDS are the limit; it can be
+	// one high only where the scalar-register file is (7 or 8 per CU)
+	if (per_cu >= 7)
+		per_cu -= 1;
+	if (per_cu < 1 || cus < 1)
+		return -1;
+	cached = per_cu * cus;
+	return cached;
+}
+
+static bool two_pass_forced()
+{
+	const char *e = getenv("OROCH_HIP_TWO_PASS");
+	return e && e[0] == '1';
 }
 
 } // namespace oroch_hip
@@ -887,7 +1400,8 @@ extern "C" int oroch_group_select(int dtype, const void *src, size_t n, oroch_bl
 		using E = decltype(e);
 		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
 		profile_scope ps(OROCH_K_SELECT, st);
-		hipLaunchKernelGGL(k_select<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
+		const unsigned sgrid = grid < 256u * 8u * 4u ? grid : 256u * 8u * 4u;
+		hipLaunchKernelGGL(k_select<E>, dim3(sgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const typename E::S *>(src), n, nb, desc,
 				   static_cast<uint32_t *>(nullptr));
 		return int(hipGetLastError());
@@ -920,30 +1434,74 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 		return rc;
 	}
 	group_ws w = carve_ws(workspace, n);
-	rc = dispatch_dtype(dtype, [&](auto e) {
-		using E = decltype(e);
-		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
-		int r;
-		{
-			profile_scope ps(OROCH_K_SELECT, st);
-			hipLaunchKernelGGL(k_select<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
-					   static_cast<const typename E::S *>(src), n, nb, w.desc, w.sizes);
-			r = int(hipGetLastError());
+	auto two_pass = [&]() {
+		return dispatch_dtype(dtype, [&](auto e) {
+			using E = decltype(e);
+			const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+			int r;
+			{
+				profile_scope ps(OROCH_K_SELECT, st);
+				const unsigned sgrid = grid < 256u * 8u * 4u ? grid : 256u * 8u * 4u;
+				hipLaunchKernelGGL(k_select<E>, dim3(sgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
+						   static_cast<const typename E::S *>(src), n, nb, w.desc, w.sizes);
+				r = int(hipGetLastError());
+			}
+			if (r)
+				return r;
+			{
+				profile_scope ps(OROCH_K_SCAN, st);
+				r = launch_scan<uint32_t, 0>(w.sizes, nb, w.tile_sums, w.total, offsets, st);
+			}
+			if (r)
+				return r;
+			profile_scope ps(OROCH_K_ENCODE, st);
+			hipLaunchKernelGGL(k_encode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
+					   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
+					   static_cast<uint8_t *>(dst));
+			return int(hipGetLastError());
+		});
+	};
+	auto single_pass = [&]() {
+		return dispatch_dtype(dtype, [&](auto e) {
+			using E = decltype(e);
+			constexpr int per_tile = FUSED_WAVES * fused_blocks_per_wave<E>();
+			const size_t ntiles = (nb + per_tile - 1) / per_tile;
+			const int resident = fused_resident_workgroups<E>();
+			if (resident <= 0)
+				return int(hipErrorInvalidValue);
+			const unsigned grid = unsigned(ntiles < size_t(resident) ? ntiles : size_t(resident));
+			int r = int(hipMemsetAsync(w.abort_flag, 0, w.state_bytes, st));
+			if (r)
+				return r;
+			{
+				profile_scope ps(OROCH_K_ENCODE, st);
+				hipLaunchKernelGGL(k_encode_fused<E>, dim3(grid), dim3(WAVE * FUSED_WAVES), 0, st,
+						   static_cast<const typename E::S *>(src), n, nb, ntiles,
+						   static_cast<uint8_t *>(dst), offsets, w.state, w.abort_flag);
+				r = int(hipGetLastError());
+			}
+			if (r)
+				return r;
+			hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, st, w.abort_flag, offsets, nb);
+			return int(hipGetLastError());
+		});
+	};
+	const bool force_two_pass = two_pass_forced();
+	rc = force_two_pass ? two_pass() : single_pass();
+	if (rc == 0 && total_host && !force_two_pass) {
+		// the only place the host can see that the single-pass kernel gave up
+		uint64_t total = 0;
+		rc = int(hipMemcpyAsync(&total, offsets + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+		if (rc == 0)
+			rc = int(hipStreamSynchronize(st));
+		if (rc)
+			return rc;
+		if (total != ~uint64_t(0)) {
+			*total_host = total;
+			return 0;
 		}
-		if (r)
-			return r;
-		{
-			profile_scope ps(OROCH_K_SCAN, st);
-			r = launch_scan<uint32_t, 0>(w.sizes, nb, w.tile_sums, w.total, offsets, st);
-		}
-		if (r)
-			return r;
-		profile_scope ps(OROCH_K_ENCODE, st);
-		hipLaunchKernelGGL(k_encode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
-				   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
-				   static_cast<uint8_t *>(dst));
-		return int(hipGetLastError());
-	});
+		rc = two_pass();
+	}
 	if (rc == 0 && total_host) {
 		rc = int(hipMemcpyAsync(total_host, offsets + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 		if (rc == 0)
