@@ -63,6 +63,7 @@ struct width_table
 {
 	uint32_t cap[65];
 	uint32_t magic[65];
+	uint32_t magic16[65];  // ceil(2^16 / capacity): floor(x / cap) == (x * magic16) >> 16 for x < 512
 };
 
 constexpr width_table make_width_table()
@@ -70,10 +71,12 @@ constexpr width_table make_width_table()
 	width_table t{};
 	t.cap[0] = 1;
 	t.magic[0] = 0;
+	t.magic16[0] = 0;
 	for (uint32_t b = 1; b <= 64; b++) {
 		uint32_t c = 128u / b;
 		t.cap[b] = c;
 		t.magic[b] = uint32_t(((uint64_t(1) << 32) + c - 1) / c);
+		t.magic16[b] = (65536u + c - 1) / c;
 	}
 	return t;
 }
@@ -146,11 +149,26 @@ __device__ __forceinline__ typename E::C unzz(typename E::C u)
 		return ((u >> 1) ^ (C(0) - (u & 1))) & E::MASK;
 }
 
-// bitpck.h:61-71 -- 16 * ceil(n / capacity(nbits)); nbits in 1..64, n < 2^25.
-__device__ __forceinline__ uint32_t pck_space(uint32_t n, uint32_t nbits)
+// The width table copied into LDS by each workgroup: {capacity, magic,
+// magic16, space of 256 values} per width.  Kernels index it from LDS rather
+// than from constant memory: a dynamically indexed LDS read costs one DS
+// instruction, where a scalar load stalls the wave on the shared LDS/scalar
+// counter.
+__device__ __forceinline__ void load_width_table(uint4 *wt)
 {
-	uint32_t c = g_width.cap[nbits];
-	return 16u * __umulhi(n + c - 1u, g_width.magic[nbits]);
+	for (int i = threadIdx.x; i < 65; i += blockDim.x) {
+		const uint32_t c = g_width.cap[i];
+		wt[i] = make_uint4(c, g_width.magic[i], g_width.magic16[i],
+				   i ? 16u * ((256u + c - 1u) / c) : 0u);
+	}
+	__syncthreads();
+}
+
+// bitpck.h:61-71 -- 16 * ceil(n / capacity(nbits)); nbits in 1..64, n < 2^25.
+__device__ __forceinline__ uint32_t pck_space(const uint4 *wt, uint32_t n, uint32_t nbits)
+{
+	const uint4 e = wt[nbits];
+	return 16u * __umulhi(n + e.x - 1u, e.y);
 }
 
 // ---- wavefront primitives -------------------------------------------------
@@ -268,12 +286,12 @@ __device__ __forceinline__ uint32_t shfl_down_zero(uint32_t x, int o, int lane)
 
 // Orders this wavefront's LDS traffic: what lanes wrote before is visible to
 // what any lane of the same wavefront reads after.  The hardware executes a
-// wavefront's DS instructions in order, so only the compiler needs telling.
+// wavefront's DS instructions in issue order, so the only thing to stop is the
+// compiler moving accesses across this point.  (A fence builtin would also
+// wait for every global load in flight, which defeats prefetching.)
 __device__ __forceinline__ void wave_sync()
 {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	asm volatile("" ::: "memory");
 }
 
 // ---- bit-granular access to a byte image held in LDS -----------------------

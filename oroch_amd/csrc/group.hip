@@ -25,6 +25,21 @@ constexpr int WAVES_PER_WG = 4;
 static_assert(BLOCK == OROCH_BLOCK_VALUES, "block size mismatch");
 static_assert(sizeof(oroch_block_desc) == 32, "descriptor layout");
 
+// min(x, cap) for a 64-bit x and a small cap, written with 32-bit compares:
+// there is no scalar 64-bit less-than on this target, and the vector compare
+// the compiler substitutes for a wave-uniform one has been seen paired with a
+// scalar select on a stale condition bit.
+__device__ __forceinline__ uint32_t clamp_u64(uint64_t x, uint32_t cap)
+{
+	const uint32_t lo = uint32_t(x), hi = uint32_t(x >> 32);
+	return hi ? cap : (lo < cap ? lo : cap);
+}
+// Values in block number blk of an n-value array.
+__device__ __forceinline__ int block_count(size_t n, size_t blk)
+{
+	return int(clamp_u64(uint64_t(n) - uint64_t(blk) * BLOCK, uint32_t(BLOCK)));
+}
+
 // Wave-uniform outcome of selection for one block.
 template <typename C>
 struct selection
@@ -129,7 +144,7 @@ __device__ __forceinline__ int prev_exception(const bool (&f)[VPL], int lane)
 // FULL: the block holds all 256 values (every lane's four are valid).
 template <typename E, bool FULL>
 __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, uint32_t *hist,
-			     selection<typename E::C> &sel)
+			     const uint4 *wt, selection<typename E::C> &sel)
 {
 	using C = typename E::C;
 
@@ -193,7 +208,7 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 			zmax = a > b ? a : b;
 		}
 		uint32_t nb = bitlen(zmax);
-		uint32_t total = pck_space(nv, nb) + 1;
+		uint32_t total = pck_space(wt, nv, nb) + 1;
 		if (total < best) {
 			best = total;
 			bmeta0 = 1;
@@ -204,7 +219,7 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	}
 	const uint32_t nbmax = bitlen(C((mx - mn) & E::MASK));
 	{
-		uint32_t total = pck_space(nv, nbmax) + 1 + vo;
+		uint32_t total = pck_space(wt, nv, nbmax) + 1 + vo;
 		if (total < best) {
 			best = total;
 			bmeta0 = 1 + vo;
@@ -267,12 +282,12 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	const uint32_t basic_meta = 1 + vo;
 	const uint32_t bw = active ? b : 1u;
 	const uint32_t xmeta = 2 + vsp_bits(bitlen(nout));
-	const uint32_t valpck = pck_space(nout, active ? nbmax - b : 1u);
+	const uint32_t valpck = pck_space(wt, nout, active ? nbmax - b : 1u);
 	const uint32_t venc = valpck < valvar ? OROCH_BITPCK : OROCH_VARINT;
 	const uint32_t vdata = valpck < valvar ? valpck : valvar;
-	uint32_t indmin = pck_space(nout, 1);
+	uint32_t indmin = pck_space(wt, nout, 1);
 	indmin = indmin > uint32_t(nv) ? uint32_t(nv) : indmin;
-	const uint32_t fixed = basic_meta + xmeta + pck_space(nv, bw) + vdata;
+	const uint32_t fixed = basic_meta + xmeta + pck_space(wt, nv, bw) + vdata;
 	const uint32_t est = fixed + indmin;
 
 	// Replay of the reference's ascending loop.  `best` only shrinks, so a
@@ -313,7 +328,7 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 		const uint32_t indvar = wave_sum(gsum);
 		uint32_t indnbits = bitlen(gmax);
 		indnbits = indnbits ? indnbits : 1u;
-		const uint32_t indpck = pck_space(noutL, indnbits);
+		const uint32_t indpck = pck_space(wt, noutL, indnbits);
 		const uint32_t ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
 		const uint32_t idata = indpck < indvar ? indpck : indvar;
 
@@ -359,11 +374,11 @@ struct lane_consts
 	uint32_t pck256;  // bitpck space of 256 values at lane + 1 bits
 };
 
-__device__ __forceinline__ lane_consts make_lane_consts(int lane)
+__device__ __forceinline__ lane_consts make_lane_consts(const uint4 *wt, int lane)
 {
 	lane_consts lc;
 	lc.w = vsp_bits(uint32_t(lane) + 1);
-	lc.pck256 = pck_space(BLOCK, uint32_t(lane) + 1);
+	lc.pck256 = wt[lane + 1].w;
 	return lc;
 }
 
@@ -371,7 +386,7 @@ __device__ __forceinline__ lane_consts make_lane_consts(int lane)
 // wt: {capacity, magic} per width, shared by the workgroup (width_table in LDS).
 // ud[]: bit lengths of the deltas, for the caller.
 template <typename E>
-__device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *hq, const uint2 *wt,
+__device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *hq, const uint4 *wt,
 			    const lane_consts &lc, selection<typename E::C> &sel)
 {
 	using C = typename E::C;
@@ -482,7 +497,7 @@ __device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *h
 	const bool active = b < nbmax && h.x != 0;
 	const uint32_t basic_meta = 1 + vo;
 	const uint32_t xmeta = 2 + (nout < 128u ? 1u : 2u);
-	const uint2 cm = wt[active ? nbmax - b : 1u];
+	const uint4 cm = wt[active ? nbmax - b : 1u];
 	const uint32_t valpck = 16u * __umulhi(nout + cm.x - 1u, cm.y);
 	const uint32_t venc = valpck < valvar ? OROCH_BITPCK : OROCH_VARINT;
 	const uint32_t vdata = valpck < valvar ? valpck : valvar;
@@ -534,7 +549,7 @@ __device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *h
 		}
 		uint32_t indpck = ~0u;
 		if (indnbits) {
-			const uint2 ci = wt[indnbits];
+			const uint4 ci = wt[indnbits];
 			indpck = 16u * __umulhi(noutL + uniform(ci.x) - 1u, uniform(ci.y));
 		}
 		const uint32_t ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
@@ -616,7 +631,7 @@ __device__ __forceinline__ uint32_t put_varint(uint8_t *img, uint32_t pos, uint6
 // into `img` (LDS, 16-byte aligned, zero filled here) and returns its length.
 template <typename E, bool FULL>
 __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane,
-				 const selection<typename E::C> &sel, uint32_t *img)
+				 const selection<typename E::C> &sel, const uint4 *wt, uint32_t *img)
 {
 	using C = typename E::C;
 	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
@@ -631,10 +646,14 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 	// metadata, integer_codec.h:128-151, 177-182, 196-204: at most 16 bytes,
 	// assembled in two scalar registers and stored by one lane
 	{
-		uint64_t h[2] = {sel.encoding, 0};
+		uint64_t h0 = sel.encoding, h1 = 0;
 		uint32_t p = 1;
 		auto put = [&](uint32_t byte) {
-			h[p >> 3] |= uint64_t(byte) << ((p & 7u) * 8u);
+			const uint64_t x = uint64_t(byte) << ((p & 7u) * 8u);
+			if (p & 8u)
+				h1 |= x;
+			else
+				h0 |= x;
 			p++;
 		};
 		auto put_var = [&](uint64_t u) {
@@ -667,9 +686,9 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 		}
 		if (lane == 0) {
 			uint64_t *img64 = reinterpret_cast<uint64_t *>(img);
-			img64[0] = h[0];
+			img64[0] = h0;
 			if (p > 8)
-				img64[1] = h[1];
+				img64[1] = h1;
 		}
 	}
 
@@ -684,7 +703,7 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 	} else if (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) {
 		// bitpck.h:73-128: value k of a 16-byte block at bit k * nbits
 		const uint32_t nb = sel.nbits;
-		const uint32_t cap = g_width.cap[nb], magic = g_width.magic[nb];
+		const uint32_t cap = uniform(wt[nb].x), magic = uniform(wt[nb].y);
 		const C low = nb >= uint32_t(E::W) ? E::MASK : C((C(1) << (nb % E::W)) - 1);
 		C u[VPL];
 		bool f[VPL];
@@ -720,15 +739,14 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 				}
 			}
 			uint32_t run = wave_scan_sum(acc, lane) - acc; // exclusive
-			const uint32_t ibase = doff + pck_space(uint32_t(nv), nb);
+			const uint32_t ibase = doff + pck_space(wt, uint32_t(nv), nb);
 			const uint32_t ilen = sel.ienc == OROCH_BITPCK
-						      ? pck_space(sel.noutliers, sel.inbits)
+						      ? pck_space(wt, sel.noutliers, sel.inbits)
 						      : (wave_sum(acc) >> 10) & 0x3ffu;
 			const uint32_t vbase = ibase + ilen;
-			const uint32_t icap = g_width.cap[sel.inbits ? sel.inbits : 1u];
-			const uint32_t imagic = g_width.magic[sel.inbits ? sel.inbits : 1u];
-			const uint32_t vcap = g_width.cap[sel.vnbits ? sel.vnbits : 1u];
-			const uint32_t vmagic = g_width.magic[sel.vnbits ? sel.vnbits : 1u];
+			const uint4 iw = wt[sel.inbits ? sel.inbits : 1u], vw = wt[sel.vnbits ? sel.vnbits : 1u];
+			const uint32_t icap = uniform(iw.x), imagic = uniform(iw.y);
+			const uint32_t vcap = uniform(vw.x), vmagic = uniform(vw.y);
 #pragma unroll
 			for (int s = 0; s < VPL; s++) {
 				if (f[s]) {
@@ -782,25 +800,17 @@ __device__ __forceinline__ void flush_image(const uint32_t *img, uint32_t len, u
 
 // ---- kernels ----------------------------------------------------------------------
 
-// Copies the width table into LDS (dynamic per-lane indexing is cheap there).
-__device__ __forceinline__ void load_width_table(uint2 *wt)
-{
-	for (int i = threadIdx.x; i < 65; i += blockDim.x)
-		wt[i] = make_uint2(g_width.cap[i], g_width.magic[i]);
-	__syncthreads();
-}
-
 // Selection for the block in v[]: the lean path for full blocks, the general
 // one for a short last block.
 template <typename E>
 __device__ __forceinline__ void select_any(const typename E::C (&v)[VPL], int nv, int lane,
-					   uint32_t *hq, const uint2 *wt, const lane_consts &lc,
+					   uint32_t *hq, const uint4 *wt, const lane_consts &lc,
 					   selection<typename E::C> &sel)
 {
 	if (nv == BLOCK)
 		select_full<E>(v, lane, hq, wt, lc, sel);
 	else
-		select_block<E, false>(v, nv, lane, hq, sel);
+		select_block<E, false>(v, nv, lane, hq, wt, sel);
 }
 
 template <typename E>
@@ -809,14 +819,14 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select(const typename E:
 								 uint32_t *sizes)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t hist2[WAVES_PER_WG][264];
-	__shared__ uint2 wt[65];
+	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
 	load_width_table(wt);
-	const lane_consts lc = make_lane_consts(lane);
+	const lane_consts lc = make_lane_consts(wt, lane);
 	for (size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave; blk < nblocks;
 	     blk += size_t(gridDim.x) * WAVES_PER_WG) {
 		const size_t base = blk * BLOCK;
-		const int nv = int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
+		const int nv = block_count(n, blk);
 		typename E::C v[VPL];
 		load_block<E>(src, base, nv, lane, v);
 		selection<typename E::C> sel;
@@ -837,20 +847,23 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode(const typename E:
 								 const uint64_t *offsets, uint8_t *dst)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
+	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
-	const size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
-	if (blk >= nblocks)
-		return;
-	const size_t base = blk * BLOCK;
-	const int nv = int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
-	typename E::C v[VPL];
-	load_block<E>(src, base, nv, lane, v);
-	selection<typename E::C> sel;
-	get_desc(&desc[blk], sel);
-	const uint64_t off = uniform(offsets[blk]);
-	const uint32_t len = nv == BLOCK ? encode_block<E, true>(v, nv, lane, sel, image[wave])
-					 : encode_block<E, false>(v, nv, lane, sel, image[wave]);
-	flush_image(image[wave], len, dst + off, lane);
+	load_width_table(wt);
+	for (size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave; blk < nblocks;
+	     blk += size_t(gridDim.x) * WAVES_PER_WG) {
+		const size_t base = blk * BLOCK;
+		const int nv = block_count(n, blk);
+		typename E::C v[VPL];
+		load_block<E>(src, base, nv, lane, v);
+		selection<typename E::C> sel;
+		get_desc(&desc[blk], sel);
+		const uint64_t off = uniform(offsets[blk]);
+		const uint32_t len = nv == BLOCK ? encode_block<E, true>(v, nv, lane, sel, wt, image[wave])
+						 : encode_block<E, false>(v, nv, lane, sel, wt, image[wave]);
+		flush_image(image[wave], len, dst + off, lane);
+		wave_sync();
+	}
 }
 
 // ---- single-pass encode ----------------------------------------------------------------
@@ -942,14 +955,14 @@ __global__ __launch_bounds__(WAVE *FUSED_WAVES) void k_encode_fused(
 	constexpr int ARENA = R * IMG + 16;
 	__shared__ __attribute__((aligned(16))) uint32_t arena[FUSED_WAVES][ARENA / 4];
 	__shared__ __attribute__((aligned(16))) uint32_t hist2[FUSED_WAVES][264];
-	__shared__ uint2 wt[65];
+	__shared__ uint4 wt[65];
 	__shared__ uint32_t blkpos[FUSED_WAVES][R];
 	__shared__ uint32_t wave_total[FUSED_WAVES];
 	__shared__ uint64_t tile_base;
 	__shared__ uint32_t aborted;
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
 	load_width_table(wt);
-	const lane_consts lc = make_lane_consts(lane);
+	const lane_consts lc = make_lane_consts(wt, lane);
 
 	// The wave's blocks in the order it meets them: tile blockIdx.x + (j / R) *
 	// gridDim.x, block j % R of the wave's share.  Loads run two blocks ahead of
@@ -960,10 +973,7 @@ __global__ __launch_bounds__(WAVE *FUSED_WAVES) void k_encode_fused(
 		return tile < ntiles ? (tile * FUSED_WAVES + wave) * R + j % R : nblocks;
 	};
 	auto count_of = [&](size_t blk) -> int {
-		if (blk >= nblocks)
-			return 0;
-		const size_t base = blk * BLOCK;
-		return int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
+		return blk < nblocks ? block_count(n, blk) : 0;
 	};
 #ifdef OROCH_EXP_STAGGER
 	// spread the workgroups' phases over one tile time so that the tiles of a
@@ -994,9 +1004,9 @@ __global__ __launch_bounds__(WAVE *FUSED_WAVES) void k_encode_fused(
 				uint32_t len;
 				select_any<E>(v, nv, lane, hist2[wave], wt, lc, sel);
 				if (nv == BLOCK)
-					len = encode_block<E, true>(v, nv, lane, sel, arena[wave] + pos / 4);
+					len = encode_block<E, true>(v, nv, lane, sel, wt, arena[wave] + pos / 4);
 				else
-					len = encode_block<E, false>(v, nv, lane, sel, arena[wave] + pos / 4);
+					len = encode_block<E, false>(v, nv, lane, sel, wt, arena[wave] + pos / 4);
 				pos += (len + 15u) & ~15u;
 			}
 #pragma unroll
@@ -1125,49 +1135,69 @@ __device__ uint32_t varint_list_decode(const uint8_t *img8, uint32_t start, uint
 	return pos - start;
 }
 
-template <typename E>
-__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *src,
-								 const uint64_t *offsets, size_t n,
-								 size_t nblocks, typename E::S *dst)
+#ifdef OROCH_DEBUG_DECODE2
+__device__ uint32_t *g_dbg = nullptr;
+extern "C" __global__ void k_set_dbg(uint32_t *p) { g_dbg = p; }
+#endif
+
+// Byte p (0..15) of a 16-byte header held in two scalar registers.  (Plain
+// variables, not an array: a dynamically indexed private array is moved to
+// memory by the compiler and everything derived from it stops being scalar.)
+__device__ __forceinline__ uint32_t hdr_byte(uint64_t h0, uint64_t h1, uint32_t p)
+{
+	const uint64_t w = (p & 8u) ? h1 : h0;
+	return uint32_t(w >> ((p & 7u) * 8u)) & 0xffu;
+}
+// varint.h:85-115 from the header registers; advances p.
+__device__ __forceinline__ uint64_t hdr_varint(uint64_t h0, uint64_t h1, uint32_t &p)
+{
+	uint64_t value = 0;
+	uint32_t shift = 0;
+	for (;;) {
+		const uint32_t byte = hdr_byte(h0, h1, p);
+		p++;
+		if (shift < 64)
+			value |= uint64_t(byte & 0x7fu) << shift;
+		shift += 7;
+		if ((byte & 0x80u) == 0 || shift > 70)
+			break;
+	}
+	return value;
+}
+
+// Decodes the block whose image (len bytes) sits in `img`.  FULL: 256 values.
+template <typename E, bool FULL>
+__device__ void decode_block(uint32_t *img, uint32_t len, int nv, int lane, typename E::C *val,
+			     uint32_t *gp, const uint4 *wt, typename E::C (&v)[VPL])
 {
 	using C = typename E::C;
-	// image: the block's bytes; vals: one slot per value (list scratch, patches)
-	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
-	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK];
-	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
-	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
-	const size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
-	if (blk >= nblocks)
-		return;
-	const size_t base = blk * BLOCK;
-	const int nv = int(n - base < size_t(BLOCK) ? n - base : size_t(BLOCK));
-	const uint64_t off = uniform(offsets[blk]);
-	uint32_t len = uint32_t(uniform(offsets[blk + 1]) - off);
-	const uint32_t maxlen = uint32_t(image_bytes<E>() - 16);
-	len = len > maxlen ? maxlen : len;
-	uint32_t *img = image[wave];
 	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
-	for (uint32_t o = uint32_t(lane) * 16u; o < len; o += WAVE * 16u)
-		*reinterpret_cast<uint4 *>(img8 + o) = *reinterpret_cast<const uint4 *>(src + off + o);
-	wave_sync();
 
-	// metadata, integer_codec.h:153-175, 184-194, 206-214 (every lane parses)
-	uint32_t p = 0;
-	const uint32_t enc = img8[p++];
+	// metadata, integer_codec.h:153-175, 184-194, 206-214: the first 16 bytes,
+	// read once and parsed in scalar registers
+	const uint4 hw = *reinterpret_cast<const uint4 *>(img);
+	const uint64_t h0 = (uint64_t(uniform(hw.y)) << 32) | uniform(hw.x);
+	const uint64_t h1 = (uint64_t(uniform(hw.w)) << 32) | uniform(hw.z);
+	uint32_t p = 1;
+	const uint32_t enc = uint32_t(h0) & 0xffu;
 	C origin = 0;
 	uint32_t nb = 0, nout = 0, inb = 0, vnb = 0;
 	if (enc == OROCH_NAUGHT || enc == OROCH_VARFOR || enc == OROCH_BITFOR || enc == OROCH_BITPFR)
-		origin = unzz<E>(C(get_varint(img8, p)) & E::MASK);
+		origin = unzz<E>(C(hdr_varint(h0, h1, p)) & E::MASK);
 	if (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR)
-		nb = img8[p++];
+		nb = hdr_byte(h0, h1, p++);
 	if (enc == OROCH_BITPFR) {
-		nout = uint32_t(get_varint(img8, p));
-		inb = img8[p++];
-		vnb = img8[p++];
+		nout = uint32_t(hdr_varint(h0, h1, p));
+		inb = hdr_byte(h0, h1, p++);
+		vnb = hdr_byte(h0, h1, p++);
 	}
 	const uint32_t doff = (p + 7u) & ~7u; // integer_group.h:70-72
+#ifdef OROCH_DEBUG_DECODE
+	if (lane == 0)
+		printf("dec: enc %u nb %u nout %u inb %u vnb %u doff %u len %u nv %d h0 %llx\n", enc, nb, nout, inb,
+		       vnb, doff, len, nv, (unsigned long long) h0);
+#endif
 
-	C v[VPL];
 #pragma unroll
 	for (int s = 0; s < VPL; s++)
 		v[s] = 0;
@@ -1184,18 +1214,19 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *sr
 		const typename E::S *raw = reinterpret_cast<const typename E::S *>(img8 + doff);
 #pragma unroll
 		for (int s = 0; s < VPL; s++)
-			if (lane * VPL + s < nv)
+			if (FULL || lane * VPL + s < nv)
 				v[s] = raw[lane * VPL + s];
 	} else if ((enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) && sane) {
 		// bitpck.h:171-201 as a bit-field read
-		const uint32_t cap = g_width.cap[nb], magic = g_width.magic[nb];
+		const uint4 we = wt[nb];
+		const uint32_t cap = uniform(we.x), m16 = uniform(we.z);
 		C u[VPL];
 #pragma unroll
 		for (int s = 0; s < VPL; s++) {
 			const uint32_t pos = uint32_t(lane * VPL + s);
 			u[s] = 0;
-			if (pos < uint32_t(nv)) {
-				const uint32_t blkn = __umulhi(pos, magic);
+			if (FULL || pos < uint32_t(nv)) {
+				const uint32_t blkn = (pos * m16) >> 16;
 				const uint32_t k = pos - blkn * cap;
 				u[s] = lds_get_bits<C>(img, doff * 8u + blkn * 128u + k * nb, nb) & E::MASK;
 			}
@@ -1203,30 +1234,33 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *sr
 		if (enc == OROCH_BITPFR && nout > 0 && nout <= uint32_t(nv) && vnb <= uint32_t(E::W) &&
 		    inb <= 64) {
 			// integer_codec.h:583-609, bitpfr.h:114-124
-			C *val = vals[wave];
-			uint32_t *gp = gaps[wave];
-			const uint32_t ibase = doff + pck_space(uint32_t(nv), nb);
-			for (int i = lane; i < BLOCK; i += WAVE) {
+			const uint32_t ibase = doff + pck_space(wt, uint32_t(nv), nb);
+			// list slots are filled by OR, so the ones in use start at zero
+#ifdef OROCH_EXP_FULLZERO
+			for (uint32_t i = uint32_t(lane); i < BLOCK; i += WAVE) {
+#else
+			for (uint32_t i = uint32_t(lane); i < nout; i += WAVE) {
+#endif
 				val[i] = 0;
 				gp[i] = 0;
 			}
 			wave_sync();
 			uint32_t ilen;
 			if (inb) {
-				const uint32_t icap = g_width.cap[inb], imagic = g_width.magic[inb];
+				const uint32_t icap = uniform(wt[inb].x), imagic = uniform(wt[inb].y);
 				for (uint32_t e = uint32_t(lane); e < nout; e += WAVE) {
 					const uint32_t bk = __umulhi(e, imagic);
 					gp[e] = uint32_t(lds_get_bits64(img, ibase * 8u + bk * 128u + (e - bk * icap) * inb,
 								       inb));
 				}
-				ilen = pck_space(nout, inb);
+				ilen = pck_space(wt, nout, inb);
 				wave_sync();
 			} else {
 				ilen = varint_list_decode<uint32_t>(img8, ibase, len, nout, gp, lane);
 			}
 			const uint32_t vbase = ibase + ilen;
 			if (vnb) {
-				const uint32_t vcap = g_width.cap[vnb], vmagic = g_width.magic[vnb];
+				const uint32_t vcap = uniform(wt[vnb].x), vmagic = uniform(wt[vnb].y);
 				for (uint32_t e = uint32_t(lane); e < nout; e += WAVE) {
 					const uint32_t bk = __umulhi(e, vmagic);
 					val[e] = lds_get_bits<C>(img, vbase * 8u + bk * 128u + (e - bk * vcap) * vnb, vnb);
@@ -1242,17 +1276,33 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *sr
 			uint32_t epos[VPL];
 #pragma unroll
 			for (int it = 0; it < VPL; it++) {
-				const uint32_t e = uint32_t(it * WAVE + lane);
-				const uint32_t step = e < nout ? gp[e] + 1u : 0u;
-				const uint32_t incl = wave_scan_sum(step, lane) + carry;
-				carry = uniform(uint32_t(__shfl(incl, WAVE - 1, WAVE)));
-				epos[it] = e < nout ? incl - 1u : ~0u;
-				hi[it] = e < nout ? val[e] : C(0);
+				hi[it] = 0;
+				epos[it] = ~0u;
+				if (uint32_t(it * WAVE) < nout) {
+					const uint32_t e = uint32_t(it * WAVE + lane);
+					const uint32_t step = e < nout ? gp[e] + 1u : 0u;
+					const uint32_t incl = wave_scan_sum(step, lane) + carry;
+					carry = read_lane(incl, WAVE - 1);
+					epos[it] = e < nout ? incl - 1u : ~0u;
+					hi[it] = e < nout ? val[e] : C(0);
+				}
 			}
+#ifdef OROCH_DEBUG_DECODE2
+			if (lane == 0 && g_dbg) {
+				g_dbg[0] = 0xabcd; g_dbg[1] = uint32_t(nv); g_dbg[2] = nb; g_dbg[3] = doff; g_dbg[4] = nout;
+				g_dbg[5] = inb; g_dbg[6] = vnb; g_dbg[7] = ibase; g_dbg[8] = ilen; g_dbg[9] = vbase;
+				g_dbg[10] = len; g_dbg[11] = gp[0]; g_dbg[12] = uint32_t(val[0]); g_dbg[13] = epos[0];
+				g_dbg[14] = uint32_t(hi[0]); g_dbg[15] = uint32_t(FULL);
+			}
+#endif
 			wave_sync();
 			// the value scratch now becomes a patch table indexed by position
-			for (int i = lane; i < BLOCK; i += WAVE)
-				val[i] = 0;
+			if constexpr (sizeof(C) == 4) {
+				*reinterpret_cast<uint4 *>(&val[lane * 4]) = make_uint4(0, 0, 0, 0);
+			} else {
+				for (int i = lane; i < BLOCK; i += WAVE)
+					val[i] = 0;
+			}
 			wave_sync();
 #pragma unroll
 			for (int it = 0; it < VPL; it++)
@@ -1268,7 +1318,6 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *sr
 			v[s] = enc == OROCH_BITPCK ? unzz<E>(u[s]) : C((u[s] + origin) & E::MASK);
 	} else if (enc == OROCH_VARINT || enc == OROCH_VARFOR) {
 		// varint.h:141-147
-		C *val = vals[wave];
 		for (int i = lane; i < BLOCK; i += WAVE)
 			val[i] = 0;
 		wave_sync();
@@ -1279,7 +1328,101 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *sr
 			v[s] = enc == OROCH_VARINT ? unzz<E>(u) : C((u + origin) & E::MASK);
 		}
 	}
-	store_block<E>(dst, base, nv, lane, v);
+}
+
+// Persistent wavefronts, each walking blocks wave, wave + stride, ...  The
+// stream offsets are fetched two blocks ahead and the block image one block
+// ahead (into registers), so that the two dependent memory latencies of a
+// block (offset, then bytes) overlap with the decoding of earlier blocks.
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__restrict__ src,
+								 const uint64_t *__restrict__ offsets,
+								 size_t n, size_t nblocks,
+								 typename E::S *__restrict__ dst)
+{
+	using C = typename E::C;
+	constexpr uint32_t MAXLEN = uint32_t(image_bytes<E>() - 16);
+	constexpr int NCH = int((MAXLEN + 1023) / 1024); // 1 KiB pieces: one uint4 per lane each
+	// image: the block's bytes; vals: one slot per value (list scratch, patches)
+	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
+	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK];
+	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
+	__shared__ uint4 wt[65];
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	load_width_table(wt);
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
+	uint32_t *img = image[wave];
+	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+
+	// Vector loads on purpose: a scalar load would be waited for at the next
+	// LDS access (they share a counter), a vector load stays in flight.
+	auto extent = [&](size_t blk, uint64_t &off, uint64_t &end) {
+		off = 0;
+		end = 0;
+		if (blk < nblocks) {
+			const uint64_t *p = offsets + blk + (lane & 1);
+			const uint64_t x = __builtin_nontemporal_load(p);
+			off = x;
+			end = x;
+		}
+	};
+	auto resolve = [&](uint64_t &off, uint64_t end, uint32_t &len) {
+		// lane 0 holds offsets[blk], lane 1 offsets[blk + 1]
+		const uint64_t o = read_lane(off, 0), e = read_lane(end, 1);
+		off = o;
+		len = clamp_u64(e - o, MAXLEN);
+	};
+	auto fetch = [&](uint64_t off, uint32_t len, uint4 (&im)[NCH]) {
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+			im[c] = make_uint4(0, 0, 0, 0);
+			if (o < len)
+				im[c] = *reinterpret_cast<const uint4 *>(src + off + o);
+		}
+	};
+
+	size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
+	uint64_t off0, off1, off2, end0, end1, end2;
+	uint32_t len0, len1;
+	uint4 im0[NCH], im1[NCH];
+	extent(blk, off0, end0);
+	extent(blk + stride, off1, end1);
+	resolve(off0, end0, len0);
+	fetch(off0, len0, im0);
+	for (; blk < nblocks; blk += stride) {
+		extent(blk + 2 * stride, off2, end2);
+		resolve(off1, end1, len1);
+		fetch(off1, len1, im1);
+#ifdef OROCH_EXP_SYNCFETCH
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+
+		const size_t base = blk * BLOCK;
+		const int nv = block_count(n, blk);
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+			if (o < len0 || o == 0)
+				*reinterpret_cast<uint4 *>(img8 + o) = im0[c];
+		}
+		wave_sync();
+		C v[VPL];
+		if (nv == BLOCK)
+			decode_block<E, true>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
+		else
+			decode_block<E, false>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
+		store_block<E>(dst, base, nv, lane, v);
+		wave_sync();
+
+		off0 = off1;
+		len0 = len1;
+		off1 = off2;
+		end1 = end2;
+#pragma unroll
+		for (int c = 0; c < NCH; c++)
+			im0[c] = im1[c];
+	}
 }
 
 // ---- host side ----------------------------------------------------------------------
@@ -1358,10 +1501,18 @@ static int fused_resident_workgroups()
 	return cached;
 }
 
+// Which encode path runs: the single-pass kernel reads the values once but
+// currently loses more to its lower occupancy and the look-back waits than it
+// saves, so the two-pass path (select, scan, encode) is the default.
+// OROCH_HIP_SINGLE_PASS=1 selects the single-pass kernel, OROCH_HIP_TWO_PASS=1
+// forces the default explicitly.
 static bool two_pass_forced()
 {
 	const char *e = getenv("OROCH_HIP_TWO_PASS");
-	return e && e[0] == '1';
+	if (e && e[0] == '1')
+		return true;
+	const char *s = getenv("OROCH_HIP_SINGLE_PASS");
+	return !(s && s[0] == '1');
 }
 
 } // namespace oroch_hip
@@ -1400,7 +1551,7 @@ extern "C" int oroch_group_select(int dtype, const void *src, size_t n, oroch_bl
 		using E = decltype(e);
 		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
 		profile_scope ps(OROCH_K_SELECT, st);
-		const unsigned sgrid = grid < 256u * 8u * 4u ? grid : 256u * 8u * 4u;
+		const unsigned sgrid = grid < 16384u ? grid : 16384u;
 		hipLaunchKernelGGL(k_select<E>, dim3(sgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const typename E::S *>(src), n, nb, desc,
 				   static_cast<uint32_t *>(nullptr));
@@ -1441,7 +1592,7 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 			int r;
 			{
 				profile_scope ps(OROCH_K_SELECT, st);
-				const unsigned sgrid = grid < 256u * 8u * 4u ? grid : 256u * 8u * 4u;
+				const unsigned sgrid = grid < 16384u ? grid : 16384u;
 				hipLaunchKernelGGL(k_select<E>, dim3(sgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 						   static_cast<const typename E::S *>(src), n, nb, w.desc, w.sizes);
 				r = int(hipGetLastError());
@@ -1455,7 +1606,8 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 			if (r)
 				return r;
 			profile_scope ps(OROCH_K_ENCODE, st);
-			hipLaunchKernelGGL(k_encode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
+			hipLaunchKernelGGL(k_encode<E>, dim3(grid < 16384u ? grid : 16384u),
+					   dim3(WAVE * WAVES_PER_WG), 0, st,
 					   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
 					   static_cast<uint8_t *>(dst));
 			return int(hipGetLastError());
@@ -1510,6 +1662,14 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 	return rc;
 }
 
+#ifdef OROCH_DEBUG_DECODE2
+extern "C" int oroch_debug_set(uint32_t *p)
+{
+	hipLaunchKernelGGL(k_set_dbg, dim3(1), dim3(1), 0, nullptr, p);
+	return int(hipDeviceSynchronize());
+}
+#endif
+
 extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n,
 				  void *dst, void *stream)
 {
@@ -1527,7 +1687,10 @@ extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *of
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
-		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+		unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+		// more workgroups than the chip holds at once: the dispatcher then
+		// evens out blocks of different cost
+		grid = grid < 16384u ? grid : 16384u;
 		profile_scope ps(OROCH_K_DECODE, st);
 		hipLaunchKernelGGL(k_decode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const uint8_t *>(src), offsets, n, nb,

@@ -11,8 +11,8 @@ enc = oroch_amd.GroupEncoder(np.int32, n, x.device)
 back = torch.empty_like(x)
 res = {}
 for mode in ("two", "one"):
-    if mode == "two": os.environ["OROCH_HIP_TWO_PASS"] = "1"
-    else: os.environ.pop("OROCH_HIP_TWO_PASS", None)
+    if mode == "two": os.environ.pop("OROCH_HIP_SINGLE_PASS", None)
+    else: os.environ["OROCH_HIP_SINGLE_PASS"] = "1"
     for it in range(2): enc.encode(x)
     torch.cuda.synchronize()
     oroch_amd.profile_start(256)

@@ -255,18 +255,23 @@ def test_argument_errors(hip):
 
 
 def test_two_pass_path_matches_single_pass(hip, oracle):
-    # the fallback (select, scan, encode as separate launches) gives the same stream
+    # the single-pass kernel (chained scan inside one launch) and the two-pass
+    # path (select, scan, encode as separate launches) give the same stream
     import os
 
     a = np.concatenate([dg.outlier_mix(256 * 999 + 17, np.int32, seed=11, shift=-200),
                         dg.fuzz_block(np.random.default_rng(5), np.int32, 256)])
     x = dev(a)
     s1, o1 = hip.group_encode(x)
-    os.environ["OROCH_HIP_TWO_PASS"] = "1"
+    os.environ["OROCH_HIP_SINGLE_PASS"] = "1"
     try:
         s2, o2 = hip.group_encode(x)
+        big = dev(dg.outlier_mix(1 << 24, np.int32, seed=12, shift=-200))
+        b2, bo2 = hip.group_encode(big)
     finally:
-        del os.environ["OROCH_HIP_TWO_PASS"]
+        del os.environ["OROCH_HIP_SINGLE_PASS"]
+    b1, bo1 = hip.group_encode(big)
+    assert np.array_equal(host(bo1), host(bo2)) and np.array_equal(host(b1), host(b2))
     assert np.array_equal(host(o1), host(o2)) and np.array_equal(host(s1), host(s2))
     exp, exp_offs = oracle.blocks_encode(a, 256, 16)
     assert np.array_equal(host(s1), exp) and np.array_equal(host(o1).astype(np.uint64), exp_offs)
