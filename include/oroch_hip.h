@@ -72,6 +72,19 @@ typedef struct oroch_block_desc {
 	uint8_t reserved[4];
 } oroch_block_desc;
 
+/*
+ * Statistics of one block: integer_stats<T> (integer_stats.h:35-113) after its
+ * constructor and build_histogram(): count, minimum, maximum and the W + 1 bin
+ * histogram of the bit length of (v - min).
+ */
+typedef struct oroch_block_stats {
+	uint64_t min;            /* raw bits; for an empty block max() of T */
+	uint64_t max;            /* raw bits; for an empty block min() of T */
+	uint16_t nvalues;
+	uint16_t histogram[65];  /* bins W+1 .. 64 stay zero */
+	uint16_t reserved[6];
+} oroch_block_stats;
+
 /* Library / device set-up.  Selects `device`, verifies it is usable. */
 int oroch_hip_init(int device);
 /* Human-readable text for a return code of this library. */
@@ -126,7 +139,23 @@ int oroch_bitpfr_decode(int dtype, const void *src, size_t n, uint64_t origin, u
 			const uint64_t *indices, const uint64_t *values, size_t nexc, void *dst,
 			void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * bitpfr_codec<T>::decode_patch alone, bitpfr.h:114-124, on n already unpacked
+ * values in dst.
+ */
+int oroch_bitpfr_patch(int dtype, void *dst, size_t n, uint64_t origin, unsigned nbits,
+		       const uint64_t *indices, const uint64_t *values, size_t nexc,
+		       void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- per-block statistics, selection, batch encode / decode --------------- */
+
+/*
+ * integer_stats<T>, integer_stats.h:48-53 (count, min, max) and :74-80 (bit
+ * length histogram), for every block of OROCH_BLOCK_VALUES values.  stats:
+ * device array of ceil(n / block) records.
+ */
+int oroch_group_stats(int dtype, const void *src, size_t n, oroch_block_stats *stats,
+		      void *stream);
 
 /*
  * integer_codec<T>::select, integer_codec.h:234-384 (with integer_stats.h
@@ -175,6 +204,30 @@ int oroch_group_encode_host(int dtype, const void *src_host, size_t n, void *dst
 			    size_t dst_capacity, uint64_t *offsets_host, uint64_t *total_host);
 int oroch_group_decode_host(int dtype, const void *src_host, const uint64_t *offsets_host,
 			    size_t n, void *dst_host);
+/* oroch_group_select / oroch_group_stats with HOST pointers. */
+int oroch_group_select_host(int dtype, const void *src_host, size_t n,
+			    oroch_block_desc *desc_host);
+int oroch_group_stats_host(int dtype, const void *src_host, size_t n,
+			   oroch_block_stats *stats_host);
+/*
+ * The whole-sequence codecs with HOST pointers.  vcodec: 0 = bitpck (zigzag
+ * for signed T), 1 = bitfor (origin).  The bitpfr calls exchange the
+ * exception lists as host arrays of uint64_t; *nexc_host receives the count
+ * (encode needs room for n entries in each list).
+ */
+int oroch_pack_host(int dtype, int vcodec, const void *src_host, size_t n, uint64_t origin,
+		    unsigned nbits, void *dst_host);
+int oroch_unpack_host(int dtype, int vcodec, const void *src_host, size_t n, uint64_t origin,
+		      unsigned nbits, void *dst_host);
+int oroch_bitpfr_encode_host(int dtype, const void *src_host, size_t n, uint64_t origin,
+			     unsigned nbits, void *dst_host, uint64_t *indices_host,
+			     uint64_t *values_host, uint64_t *nexc_host);
+int oroch_bitpfr_decode_host(int dtype, const void *src_host, size_t n, uint64_t origin,
+			     unsigned nbits, const uint64_t *indices_host,
+			     const uint64_t *values_host, size_t nexc, void *dst_host);
+int oroch_bitpfr_patch_host(int dtype, void *dst_host, size_t n, uint64_t origin, unsigned nbits,
+			    const uint64_t *indices_host, const uint64_t *values_host,
+			    size_t nexc);
 
 /* ---- diagnostics ---------------------------------------------------------------- */
 

@@ -25,6 +25,7 @@ from .capi import (  # noqa: F401
     group_encode,
     group_encode_host,
     group_select,
+    group_stats,
     group_workspace,
     lib,
     library_path,

@@ -21,6 +21,10 @@ DESC_DTYPE = np.dtype([
     ("value_nbits", "u1"), ("reserved", "u1", (4,)),
 ])
 assert DESC_DTYPE.itemsize == 32
+# numpy record matching struct oroch_block_stats
+STATS_DTYPE = np.dtype([("min", "<u8"), ("max", "<u8"), ("nvalues", "<u2"),
+                        ("histogram", "<u2", (65,)), ("reserved", "<u2", (6,))])
+assert STATS_DTYPE.itemsize == 160
 
 
 class OrochError(RuntimeError):
@@ -59,6 +63,7 @@ def _load():
         "oroch_bitpfr_workspace": (sz, [sz]),
         "oroch_bitpfr_encode": (i, [i, vp, sz, u64, u32, vp, vp, vp, sz, vp, vp, sz, vp]),
         "oroch_bitpfr_decode": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp, vp, sz, vp]),
+        "oroch_bitpfr_patch": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp, sz, vp]),
         "oroch_group_select": (i, [i, vp, sz, vp, vp]),
         "oroch_group_bound": (sz, [i, sz]),
         "oroch_group_workspace": (sz, [i, sz]),
@@ -66,6 +71,14 @@ def _load():
         "oroch_group_decode": (i, [i, vp, vp, sz, vp, vp]),
         "oroch_group_encode_host": (i, [i, vp, sz, vp, sz, vp, vp]),
         "oroch_group_decode_host": (i, [i, vp, vp, sz, vp]),
+        "oroch_group_stats": (i, [i, vp, sz, vp, vp]),
+        "oroch_group_select_host": (i, [i, vp, sz, vp]),
+        "oroch_group_stats_host": (i, [i, vp, sz, vp]),
+        "oroch_pack_host": (i, [i, i, vp, sz, u64, u32, vp]),
+        "oroch_unpack_host": (i, [i, i, vp, sz, u64, u32, vp]),
+        "oroch_bitpfr_encode_host": (i, [i, vp, sz, u64, u32, vp, vp, vp, vp]),
+        "oroch_bitpfr_decode_host": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp]),
+        "oroch_bitpfr_patch_host": (i, [i, vp, sz, u64, u32, vp, vp, sz]),
         "oroch_hip_profile_start": (i, [i]),
         "oroch_hip_profile_stop": (i, [vp, vp]),
     }
@@ -221,6 +234,19 @@ def group_select(x):
     _check(lib.oroch_group_select(code, x.data_ptr(), n, desc.data_ptr(), _stream()))
     torch.cuda.synchronize()
     return desc.cpu().numpy().view(DESC_DTYPE)[:nb]
+
+
+def group_stats(x):
+    """Per-block statistics records as a numpy structured array (STATS_DTYPE)."""
+    import torch
+
+    code = dtype_code(x.dtype)
+    n = x.numel()
+    nb = (n + BLOCK_VALUES - 1) // BLOCK_VALUES
+    out = torch.zeros(max(nb, 1) * STATS_DTYPE.itemsize, dtype=torch.uint8, device=x.device)
+    _check(lib.oroch_group_stats(code, x.data_ptr(), n, out.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(STATS_DTYPE)[:nb]
 
 
 class GroupEncoder:

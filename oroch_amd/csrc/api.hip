@@ -286,3 +286,201 @@ extern "C" int oroch_group_decode_host(int dtype, const void *src_host,
 		return rc;
 	return staged_copy(dst_host, out.p, bytes, false, st);
 }
+
+extern "C" int oroch_group_select_host(int dtype, const void *src_host, size_t n,
+				       oroch_block_desc *desc_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n == 0)
+		return 0;
+	if (!src_host || !desc_host)
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t nblocks = (n + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
+	dev_buf in, out;
+	int rc;
+	if ((rc = in.alloc(bytes)) || (rc = out.alloc(nblocks * sizeof(oroch_block_desc))))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, bytes, true, nullptr)))
+		return rc;
+	if ((rc = oroch_group_select(dtype, in.p, n, static_cast<oroch_block_desc *>(out.p), nullptr)))
+		return rc;
+	return staged_copy(desc_host, out.p, nblocks * sizeof(oroch_block_desc), false, nullptr);
+}
+
+extern "C" int oroch_group_stats_host(int dtype, const void *src_host, size_t n,
+				      oroch_block_stats *stats_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n == 0)
+		return 0;
+	if (!src_host || !stats_host)
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t nblocks = (n + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
+	dev_buf in, out;
+	int rc;
+	if ((rc = in.alloc(bytes)) || (rc = out.alloc(nblocks * sizeof(oroch_block_stats))))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, bytes, true, nullptr)))
+		return rc;
+	if ((rc = oroch_group_stats(dtype, in.p, n, static_cast<oroch_block_stats *>(out.p), nullptr)))
+		return rc;
+	return staged_copy(stats_host, out.p, nblocks * sizeof(oroch_block_stats), false, nullptr);
+}
+
+extern "C" int oroch_pack_host(int dtype, int vcodec, const void *src_host, size_t n,
+			       uint64_t origin, unsigned nbits, void *dst_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n == 0)
+		return 0;
+	if (!src_host || !dst_host)
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t space = oroch_bitpck_space(n, nbits);
+	if (!space)
+		return OROCH_E_NBITS;
+	dev_buf in, out;
+	int rc;
+	if ((rc = in.alloc(bytes)) || (rc = out.alloc(space)))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, bytes, true, nullptr)))
+		return rc;
+	rc = vcodec ? oroch_bitfor_encode(dtype, in.p, n, origin, nbits, out.p, nullptr)
+		    : oroch_bitpck_encode(dtype, in.p, n, nbits, out.p, nullptr);
+	if (rc)
+		return rc;
+	return staged_copy(dst_host, out.p, space, false, nullptr);
+}
+
+extern "C" int oroch_unpack_host(int dtype, int vcodec, const void *src_host, size_t n,
+				 uint64_t origin, unsigned nbits, void *dst_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n == 0)
+		return 0;
+	if (!src_host || !dst_host)
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t space = oroch_bitpck_space(n, nbits);
+	if (!space)
+		return OROCH_E_NBITS;
+	dev_buf in, out;
+	int rc;
+	if ((rc = in.alloc(space)) || (rc = out.alloc(bytes)))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, space, true, nullptr)))
+		return rc;
+	rc = vcodec ? oroch_bitfor_decode(dtype, in.p, n, origin, nbits, out.p, nullptr)
+		    : oroch_bitpck_decode(dtype, in.p, n, nbits, out.p, nullptr);
+	if (rc)
+		return rc;
+	return staged_copy(dst_host, out.p, bytes, false, nullptr);
+}
+
+extern "C" int oroch_bitpfr_encode_host(int dtype, const void *src_host, size_t n, uint64_t origin,
+					unsigned nbits, void *dst_host, uint64_t *indices_host,
+					uint64_t *values_host, uint64_t *nexc_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (!nexc_host)
+		return OROCH_E_ARGUMENT;
+	*nexc_host = 0;
+	if (n == 0)
+		return 0;
+	if (!src_host || !dst_host || !indices_host || !values_host)
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t space = oroch_bitpck_space(n, nbits);
+	if (!space)
+		return OROCH_E_NBITS;
+	dev_buf in, out, idx, val, cnt, ws;
+	int rc;
+	if ((rc = in.alloc(bytes)) || (rc = out.alloc(space)) || (rc = idx.alloc(n * 8)) ||
+	    (rc = val.alloc(n * 8)) || (rc = cnt.alloc(8)) || (rc = ws.alloc(oroch_bitpfr_workspace(n))))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, bytes, true, nullptr)))
+		return rc;
+	rc = oroch_bitpfr_encode(dtype, in.p, n, origin, nbits, out.p, static_cast<uint64_t *>(idx.p),
+				 static_cast<uint64_t *>(val.p), n, static_cast<uint64_t *>(cnt.p), ws.p,
+				 oroch_bitpfr_workspace(n), nullptr);
+	if (rc)
+		return rc;
+	if ((rc = staged_copy(nexc_host, cnt.p, 8, false, nullptr)) ||
+	    (rc = staged_copy(dst_host, out.p, space, false, nullptr)))
+		return rc;
+	if (*nexc_host) {
+		if ((rc = staged_copy(indices_host, idx.p, *nexc_host * 8, false, nullptr)) ||
+		    (rc = staged_copy(values_host, val.p, *nexc_host * 8, false, nullptr)))
+			return rc;
+	}
+	return 0;
+}
+
+extern "C" int oroch_bitpfr_decode_host(int dtype, const void *src_host, size_t n, uint64_t origin,
+					unsigned nbits, const uint64_t *indices_host,
+					const uint64_t *values_host, size_t nexc, void *dst_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n == 0)
+		return 0;
+	if (!src_host || !dst_host || (nexc && (!indices_host || !values_host)))
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t space = oroch_bitpck_space(n, nbits);
+	if (!space)
+		return OROCH_E_NBITS;
+	dev_buf in, out, idx, val, ws;
+	int rc;
+	if ((rc = in.alloc(space)) || (rc = out.alloc(bytes)) || (rc = idx.alloc(nexc * 8)) ||
+	    (rc = val.alloc(nexc * 8)) || (rc = ws.alloc(oroch_bitpfr_workspace(n))))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, space, true, nullptr)))
+		return rc;
+	if (nexc) {
+		if ((rc = staged_copy(idx.p, indices_host, nexc * 8, true, nullptr)) ||
+		    (rc = staged_copy(val.p, values_host, nexc * 8, true, nullptr)))
+			return rc;
+	}
+	rc = oroch_bitpfr_decode(dtype, in.p, n, origin, nbits, static_cast<const uint64_t *>(idx.p),
+				 static_cast<const uint64_t *>(val.p), nexc, out.p, ws.p,
+				 oroch_bitpfr_workspace(n), nullptr);
+	if (rc)
+		return rc;
+	return staged_copy(dst_host, out.p, bytes, false, nullptr);
+}
+
+extern "C" int oroch_bitpfr_patch_host(int dtype, void *dst_host, size_t n, uint64_t origin,
+				       unsigned nbits, const uint64_t *indices_host,
+				       const uint64_t *values_host, size_t nexc)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (nexc == 0)
+		return 0;
+	if (!dst_host || !indices_host || !values_host || nexc > n)
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	dev_buf out, idx, val, ws;
+	int rc;
+	if ((rc = out.alloc(bytes)) || (rc = idx.alloc(nexc * 8)) || (rc = val.alloc(nexc * 8)) ||
+	    (rc = ws.alloc(oroch_bitpfr_workspace(n))))
+		return rc;
+	if ((rc = staged_copy(out.p, dst_host, bytes, true, nullptr)) ||
+	    (rc = staged_copy(idx.p, indices_host, nexc * 8, true, nullptr)) ||
+	    (rc = staged_copy(val.p, values_host, nexc * 8, true, nullptr)))
+		return rc;
+	rc = oroch_bitpfr_patch(dtype, out.p, n, origin, nbits, static_cast<const uint64_t *>(idx.p),
+				static_cast<const uint64_t *>(val.p), nexc, ws.p,
+				oroch_bitpfr_workspace(n), nullptr);
+	if (rc)
+		return rc;
+	return staged_copy(dst_host, out.p, bytes, false, nullptr);
+}

@@ -1064,6 +1064,55 @@ __global__ void k_fused_finish(const uint32_t *abort_flag, uint64_t *offsets, si
 		offsets[nblocks] = ~uint64_t(0);
 }
 
+// ---- block statistics --------------------------------------------------------------
+//
+// integer_stats.h:48-53 (count, min, max) and :74-80, 97-102 (histogram of the
+// bit length of v - min, W + 1 bins) per block of 256 values, one wavefront per
+// block: min / max by wavefront reductions, the histogram by LDS atomics.
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_stats(const typename E::S *src, size_t n,
+								size_t nblocks, oroch_block_stats *out)
+{
+	using C = typename E::C;
+	__shared__ uint32_t hist[WAVES_PER_WG][68];
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	for (size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave; blk < nblocks;
+	     blk += size_t(gridDim.x) * WAVES_PER_WG) {
+		const int nv = block_count(n, blk);
+		C v[VPL];
+		load_block<E>(src, blk * BLOCK, nv, lane, v);
+		C kmin = ~C(0), kmax = 0;
+#pragma unroll
+		for (int s = 0; s < VPL; s++) {
+			if (lane * VPL + s < nv) {
+				const C k = v[s] ^ E::FLIP;
+				kmin = k < kmin ? k : kmin;
+				kmax = k > kmax ? k : kmax;
+			}
+		}
+		const C mn = wave_min(kmin) ^ E::FLIP, mx = wave_max(kmax) ^ E::FLIP;
+		hist[wave][lane] = 0;
+		if (lane < 4)
+			hist[wave][64 + lane] = 0;
+		wave_sync();
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			if (lane * VPL + s < nv)
+				atomicAdd(&hist[wave][bitlen(C((v[s] - mn) & E::MASK))], 1u);
+		wave_sync();
+		oroch_block_stats *o = out + blk;
+		o->histogram[lane] = uint16_t(hist[wave][lane]);
+		if (lane == 0) {
+			o->histogram[64] = uint16_t(hist[wave][64]);
+			o->nvalues = uint16_t(nv);
+			// integer_stats.h:108-109: an empty block keeps the initial values
+			o->min = nv ? uint64_t(mn) : uint64_t(E::sgn ? (E::MASK >> 1) : E::MASK);
+			o->max = nv ? uint64_t(mx) : uint64_t(E::sgn ? E::SIGN : C(0));
+		}
+		wave_sync();
+	}
+}
+
 // ---- decode -------------------------------------------------------------------------
 
 // varint.h:85-115 at a byte position of an LDS image; advances pos.
@@ -1555,6 +1604,27 @@ extern "C" int oroch_group_select(int dtype, const void *src, size_t n, oroch_bl
 		hipLaunchKernelGGL(k_select<E>, dim3(sgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const typename E::S *>(src), n, nb, desc,
 				   static_cast<uint32_t *>(nullptr));
+		return int(hipGetLastError());
+	});
+}
+
+extern "C" int oroch_group_stats(int dtype, const void *src, size_t n, oroch_block_stats *stats,
+				 void *stream)
+{
+	if (n && (!src || !stats))
+		return OROCH_E_ARGUMENT;
+	const size_t nb = nblocks_of(n);
+	if (nb == 0)
+		return 0;
+	if (nb > 0x7fffffffu * size_t(WAVES_PER_WG))
+		return OROCH_E_ARGUMENT;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+		profile_scope ps(OROCH_K_SELECT, st);
+		hipLaunchKernelGGL(k_stats<E>, dim3(grid < 16384u ? grid : 16384u), dim3(WAVE * WAVES_PER_WG),
+				   0, st, static_cast<const typename E::S *>(src), n, nb, stats);
 		return int(hipGetLastError());
 	});
 }

@@ -489,6 +489,39 @@ extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_
 	});
 }
 
+extern "C" int oroch_bitpfr_patch(int dtype, void *dst, size_t n, uint64_t origin, unsigned nbits,
+				  const uint64_t *indices, const uint64_t *values, size_t nexc,
+				  void *workspace, size_t workspace_bytes, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	const unsigned W = 8u << (dtype >> 1);
+	if (nbits < 1 || nbits >= W)
+		return OROCH_E_NBITS;
+	if (nexc == 0)
+		return 0;
+	if (nexc > n || !dst || !indices || !values || !workspace)
+		return OROCH_E_ARGUMENT;
+	if (workspace_bytes < oroch_bitpfr_workspace(n))
+		return OROCH_E_CAPACITY;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	pfr_ws w = carve_pfr(workspace, n);
+	const size_t ntiles = scan_tiles(nexc);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		using C = typename E::C;
+		profile_scope ps(OROCH_K_EXCEPT, st);
+		hipLaunchKernelGGL((k_tile_sums<uint64_t, 1>), dim3(unsigned(ntiles)), dim3(SCAN_THREADS), 0,
+				   st, indices, nexc, w.tile_sums);
+		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, w.tile_sums, ntiles,
+				   w.total);
+		hipLaunchKernelGGL(k_patch<E>, dim3(unsigned(ntiles)), dim3(SCAN_THREADS), 0, st, indices,
+				   values, nexc, w.tile_sums, C(origin & uint64_t(E::MASK)), nbits, n,
+				   static_cast<typename E::S *>(dst));
+		return int(hipGetLastError());
+	});
+}
+
 extern "C" int oroch_bitpfr_decode(int dtype, const void *src, size_t n, uint64_t origin,
 				   unsigned nbits, const uint64_t *indices, const uint64_t *values,
 				   size_t nexc, void *dst, void *workspace, size_t workspace_bytes,
@@ -506,20 +539,6 @@ extern "C" int oroch_bitpfr_decode(int dtype, const void *src, size_t n, uint64_
 	int rc = do_unpack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
 	if (rc || nexc == 0)
 		return rc;
-	hipStream_t st = static_cast<hipStream_t>(stream);
-	pfr_ws w = carve_pfr(workspace, n);
-	const size_t ntiles = scan_tiles(nexc);
-	return dispatch_dtype(dtype, [&](auto e) {
-		using E = decltype(e);
-		using C = typename E::C;
-		profile_scope ps(OROCH_K_EXCEPT, st);
-		hipLaunchKernelGGL((k_tile_sums<uint64_t, 1>), dim3(unsigned(ntiles)), dim3(SCAN_THREADS), 0,
-				   st, indices, nexc, w.tile_sums);
-		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, w.tile_sums, ntiles,
-				   w.total);
-		hipLaunchKernelGGL(k_patch<E>, dim3(unsigned(ntiles)), dim3(SCAN_THREADS), 0, st, indices,
-				   values, nexc, w.tile_sums, C(origin & uint64_t(E::MASK)), nbits, n,
-				   static_cast<typename E::S *>(dst));
-		return int(hipGetLastError());
-	});
+	return oroch_bitpfr_patch(dtype, dst, n, origin, nbits, indices, values, nexc, workspace,
+				  workspace_bytes, stream);
 }

@@ -1,0 +1,388 @@
+// host_templates_test.cc -- exercises the C++ host templates of include/oroch/
+// on the GPU and checks every byte against the CPU oracle.  The scenarios
+// follow the reference's unit tests (tests/unit/bitpck.cc, bitfor.cc,
+// bitpfr.cc, integer_codec.cc, integer_group.cc) so that a reader can put the
+// two side by side; the oracle comparisons go beyond them.
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include <oroch/integer_group.h>
+
+#include "oroch_oracle.h"
+
+static int g_checks = 0, g_failed = 0;
+
+#define REQUIRE(cond)                                                                        \
+	do {                                                                                 \
+		g_checks++;                                                                  \
+		if (!(cond)) {                                                               \
+			g_failed++;                                                          \
+			std::fprintf(stderr, "%s:%d: REQUIRE(%s) failed\n", __FILE__, __LINE__, #cond); \
+			if (g_failed > 20)                                                   \
+				std::exit(1);                                                \
+		}                                                                            \
+	} while (0)
+
+static uint64_t g_rng = 0x9e3779b97f4a7c15ull;
+static uint64_t rnd()
+{
+	uint64_t z = (g_rng += 0x9e3779b97f4a7c15ull);
+	z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+	z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+	return z ^ (z >> 31);
+}
+
+template <typename T>
+static std::vector<T> make_block(int shape, size_t n)
+{
+	using U = typename std::make_unsigned<T>::type;
+	constexpr int W = sizeof(T) * 8;
+	std::vector<T> v(n);
+	const U base = U(rnd());
+	for (size_t i = 0; i < n; i++) {
+		U u = 0;
+		switch (shape) {
+		case 0: u = base; break;                                   // constant
+		case 1: u = U(rnd()); break;                               // full range
+		case 2: u = U(rnd() & 0x3f); break;                        // small unsigned
+		case 3: u = U(base + (rnd() & 0x1f)); break;               // narrow range far from zero
+		case 4:                                                    // body plus outliers
+			u = U(base + (rnd() % 100 < 4 ? U(rnd()) >> (rnd() % (W / 2)) : U(rnd() & 0x7)));
+			break;
+		case 5: u = U(T(int64_t(rnd() % 200) - 100)); break;       // small signed
+		case 6: u = U(i * 3); break;                               // ramp
+		default: u = U(rnd() % 3 == 0 ? rnd() : 0); break;         // sparse
+		}
+		v[i] = T(u);
+	}
+	return v;
+}
+
+template <typename T>
+static void test_stats_select_group()
+{
+	const int dt = oroch::hip::dtype_of<T>();
+	constexpr int W = sizeof(T) * 8;
+	const size_t sizes[] = {1, 2, 4, 5, 8, 31, 100, 255, 256};
+	for (int shape = 0; shape < 8; shape++) {
+		for (size_t n : sizes) {
+			const std::vector<T> v = make_block<T>(shape, n);
+
+			// integer_stats against the oracle.
+			uint64_t mn, mx, hist[65];
+			orc_stats(dt, v.data(), n, &mn, &mx, hist);
+			oroch::integer_stats<T> st(v.begin(), v.end());
+			st.build_histogram(v.begin(), v.end());
+			REQUIRE(st.nvalues() == n);
+			REQUIRE(oroch::hip::raw64<T>(st.min()) == mn);
+			REQUIRE(oroch::hip::raw64<T>(st.max()) == mx);
+			for (int b = 0; b <= W; b++)
+				REQUIRE(st.histogram(b) == hist[b]);
+
+			// integer_codec::select against the oracle.
+			orc_meta om;
+			orc_select(dt, v.data(), n, &om);
+			typename oroch::integer_codec<T>::metadata meta;
+			oroch::integer_codec<T>::select(meta, v.begin(), v.end());
+			REQUIRE(meta.value_desc.encoding == om.encoding);
+			REQUIRE(meta.dataspace() == om.dataspace);
+			REQUIRE(meta.metaspace() == om.metaspace);
+			if (om.encoding != oroch::normal && om.encoding != oroch::varint
+			    && om.encoding != oroch::bitpck)
+				REQUIRE(oroch::hip::raw64<T>(meta.value_desc.origin) == om.origin);
+			if (om.encoding >= oroch::bitpck)
+				REQUIRE(meta.value_desc.nbits == om.nbits);
+			if (om.encoding == oroch::bitpfr) {
+				REQUIRE(meta.noutliers == om.noutliers);
+				REQUIRE(meta.outlier_index_desc.encoding == om.index_encoding);
+				REQUIRE(meta.outlier_value_desc.encoding == om.value_encoding);
+			}
+
+			// Metadata bytes, data bytes (integer_codec::encode) and decode.
+			std::vector<uint8_t> want(orc_group_bound(dt, n) + 64), got(want.size());
+			uint8_t mbytes[64], wbytes[64];
+			oroch::dst_bytes_t mp = mbytes;
+			meta.encode(mp);
+			const size_t wm = orc_meta_encode(dt, &om, wbytes);
+			REQUIRE(size_t(mp - mbytes) == wm);
+			REQUIRE(std::memcmp(mbytes, wbytes, wm) == 0);
+			const size_t wd = orc_codec_encode(dt, v.data(), n, &om, want.data());
+			oroch::dst_bytes_t dp = got.data();
+			oroch::integer_codec<T>::encode(dp, v.begin(), v.end(), meta);
+			REQUIRE(size_t(dp - got.data()) == wd);
+			REQUIRE(std::memcmp(got.data(), want.data(), wd) == 0);
+			std::vector<T> back(n);
+			oroch::src_bytes_t sp = got.data();
+			typename oroch::integer_codec<T>::metadata meta2;
+			oroch::src_bytes_t mq = mbytes;
+			meta2.decode(mq);
+			oroch::integer_codec<T>::decode(back.begin(), back.end(), sp, meta2);
+			REQUIRE(size_t(sp - got.data()) == wd);
+			REQUIRE(back == v);
+
+			// integer_group, aligned and not.
+			const size_t wg = orc_group_encode(dt, v.data(), n, want.data());
+			oroch::integer_group<T> group;
+			group.encode(v.begin(), v.end());
+			REQUIRE(group.size() == wg);
+			REQUIRE(std::memcmp(group.data(), want.data(), wg) == 0);
+			std::fill(back.begin(), back.end(), T(0));
+			group.decode(back.begin(), back.end());
+			REQUIRE(back == v);
+			group.encode(v.begin(), v.end(), false);
+			REQUIRE(group.size() == wm + wd);
+			std::fill(back.begin(), back.end(), T(1));
+			group.decode(back.begin(), back.end(), false);
+			REQUIRE(back == v);
+		}
+	}
+}
+
+template <typename T>
+static void test_sequences()
+{
+	const int dt = oroch::hip::dtype_of<T>();
+	constexpr unsigned W = sizeof(T) * 8;
+	using U = typename std::make_unsigned<T>::type;
+	const size_t sizes[] = {1, 7, 130, 1000, 5000};
+	for (size_t n : sizes) {
+		for (unsigned nbits : {1u, 3u, 7u, W / 2, W - 1, W}) {
+			std::vector<T> v(n);
+			// Values whose zigzag image fits nbits.
+			for (auto &x : v) {
+				const U z = nbits == W ? U(rnd()) : U(rnd() & ((U(1) << nbits) - 1));
+				x = oroch::zigzag_codec<T>::decode_if_signed(z);
+			}
+			using pck = oroch::bitpck_codec<T>;
+			std::vector<uint8_t> want(pck::space(n, nbits)), got(want.size());
+			REQUIRE(orc_bitpck_encode(dt, v.data(), n, nbits, want.data()) == want.size());
+			oroch::dst_bytes_t d = got.data();
+			pck::encode(d, v.begin(), v.end(), nbits);
+			REQUIRE(size_t(d - got.data()) == want.size());
+			REQUIRE(got == want);
+			std::vector<T> back(n);
+			oroch::src_bytes_t s = got.data();
+			pck::decode(back.begin(), back.end(), s, nbits);
+			REQUIRE(size_t(s - got.data()) == want.size());
+			REQUIRE(back == v);
+
+			// bitfor: origin anywhere, deltas fit nbits.
+			const T origin = T(U(rnd()));
+			for (auto &x : v) {
+				const U delta = nbits == W ? U(rnd()) : U(rnd() & ((U(1) << nbits) - 1));
+				x = T(U(U(origin) + delta));
+			}
+			using bfor = oroch::bitfor_codec<T>;
+			typename bfor::parameters params(origin, nbits);
+			REQUIRE(orc_bitfor_encode(dt, v.data(), n, oroch::hip::raw64<T>(origin), nbits, want.data())
+				== want.size());
+			d = got.data();
+			bfor::encode(d, v.begin(), v.end(), params);
+			REQUIRE(got == want);
+			s = got.data();
+			bfor::decode(back.begin(), back.end(), s, params);
+			REQUIRE(back == v);
+
+			// bitpfr: some deltas do not fit.
+			if (nbits == W)
+				continue;
+			for (size_t i = 0; i < n; i++)
+				if (rnd() % 16 == 0)
+					v[i] = T(U(U(origin) + U(rnd())));
+			using pfr = oroch::bitpfr_codec<T>;
+			typename pfr::exceptions x;
+			typename pfr::parameters pp(origin, nbits, x);
+			std::vector<uint64_t> wi(n), wv(n);
+			size_t wn = 0;
+			orc_bitpfr_encode(dt, v.data(), n, oroch::hip::raw64<T>(origin), nbits, want.data(),
+					  wi.data(), wv.data(), &wn);
+			d = got.data();
+			pfr::encode(d, v.begin(), v.end(), pp);
+			REQUIRE(got == want);
+			REQUIRE(x.index == n);
+			REQUIRE(x.indices.size() == wn);
+			bool same = x.indices.size() == wn;
+			for (size_t i = 0; same && i < wn; i++)
+				same = x.indices[i] == wi[i] && uint64_t(x.values[i]) == wv[i];
+			REQUIRE(same);
+			s = got.data();
+			std::fill(back.begin(), back.end(), T(0));
+			pfr::decode(back.begin(), back.end(), s, pp);
+			REQUIRE(back == v);
+			// The two halves of decode, as integer_codec.h:583-609 uses them.
+			s = got.data();
+			std::fill(back.begin(), back.end(), T(0));
+			pfr::decode_basic(back.begin(), back.end(), s, pp);
+			pfr::decode_patch(back.begin(), pp);
+			REQUIRE(back == v);
+		}
+	}
+}
+
+// tests/unit/bitpfr.cc:13-30.
+static void test_bitpfr_value_codec()
+{
+	using codec = oroch::bitpfr_codec<uint32_t>;
+	codec::exceptions excpts;
+	codec::parameters params(1000, 7, excpts);
+	params.value_encode(1000);
+	REQUIRE(excpts.index == 1);
+	REQUIRE(excpts.indices.size() == 0);
+	REQUIRE(excpts.values.size() == 0);
+	params.value_encode(1000 + (1 << 7));
+	REQUIRE(excpts.index == 2);
+	REQUIRE(excpts.indices.size() == 1);
+	REQUIRE(excpts.indices[0] == 1);
+	REQUIRE(excpts.values.size() == 1);
+	REQUIRE(excpts.values[0] == 1);
+}
+
+// tests/unit/bitpfr.cc:32-92: 128 small values, 24 growing powers of two.
+template <typename T>
+static void test_bitpfr_reference_case(T fref)
+{
+	constexpr int BITS = 7, SMALL = 128, LARGE = 24, INTS = SMALL + LARGE;
+	using codec = oroch::bitpfr_codec<T>;
+	std::array<uint8_t, codec::basic_codec::space(INTS, BITS)> bytes;
+	std::array<T, INTS> integers, integers2;
+	typename codec::exceptions excpts;
+	typename codec::parameters params(fref, BITS, excpts);
+	for (int i = 0; i < SMALL; i++)
+		integers[i] = T(i + fref);
+	for (int i = SMALL; i < INTS; i++)
+		integers[i] = T(1000 + (1 << (BITS + (i - SMALL))));
+	oroch::dst_bytes_t d_it = bytes.data();
+	codec::encode(d_it, integers.begin(), integers.end(), params);
+	REQUIRE(excpts.indices.size() == LARGE);
+	REQUIRE(excpts.values.size() == LARGE);
+	oroch::src_bytes_t b_it = bytes.data();
+	codec::decode(integers2.begin(), integers2.end(), b_it, params);
+	for (int i = 0; i < INTS; i++)
+		REQUIRE(integers2[i] == integers[i]);
+}
+
+// Two encode calls on one parameters object continue one index sequence
+// (bitpfr.h:75-85 keeps the position in the exceptions object).
+static void test_bitpfr_two_calls()
+{
+	using codec = oroch::bitpfr_codec<uint16_t>;
+	std::vector<uint16_t> v(600);
+	for (size_t i = 0; i < v.size(); i++)
+		v[i] = uint16_t(50 + (i % 37 == 5 ? 4000 + i : i % 16));
+	codec::exceptions one, two;
+	codec::parameters p1(50, 4, one), p2(50, 4, two);
+	std::vector<uint8_t> a(codec::basic_codec::space(600, 4)), b(codec::basic_codec::space(300, 4) * 2);
+	oroch::dst_bytes_t d = a.data();
+	codec::encode(d, v.begin(), v.end(), p1);
+	d = b.data();
+	codec::encode(d, v.begin(), v.begin() + 300, p2);
+	codec::encode(d, v.begin() + 300, v.end(), p2);
+	REQUIRE(one.index == 600 && two.index == 600);
+	REQUIRE(one.indices == two.indices);
+	REQUIRE(one.values == two.values);
+}
+
+// tests/unit/integer_group.cc:8-22 (fewer rounds: every call is a round trip
+// to the device).
+static void test_group_reference_case()
+{
+	oroch::integer_group<uint32_t> group;
+	std::array<uint32_t, 8> integers, integers2;
+	for (int t = 0; t < 200; t++) {
+		for (auto &x : integers)
+			x = uint32_t(rnd() & 0xfff);
+		group.encode(integers.begin(), integers.end());
+		group.decode(integers2.begin(), integers2.end());
+		REQUIRE(integers2 == integers);
+	}
+}
+
+template <typename T>
+static void test_blocks()
+{
+	const int dt = oroch::hip::dtype_of<T>();
+	for (size_t n : {size_t(0), size_t(1), size_t(256), size_t(257), size_t(70001)}) {
+		std::vector<T> v;
+		for (size_t b = 0; b * 256 < n; b++) {
+			const std::vector<T> part = make_block<T>(int(rnd() % 8), std::min<size_t>(256, n - b * 256));
+			v.insert(v.end(), part.begin(), part.end());
+		}
+		oroch::integer_blocks<T> blocks;
+		blocks.encode(v.begin(), v.end());
+		const size_t nb = (n + 255) / 256;
+		std::vector<uint8_t> want(orc_group_bound(dt, 256) * (nb + 1) + 64);
+		std::vector<uint64_t> offs(nb + 1);
+		const size_t total = orc_blocks_encode(dt, v.data(), n, 256, 16, want.data(), offs.data());
+		REQUIRE(blocks.stream().size() == total);
+		REQUIRE(blocks.offsets() == offs);
+		REQUIRE(std::memcmp(blocks.stream().data(), want.data(), total) == 0);
+		std::vector<T> back(n);
+		blocks.decode(back.begin(), back.end());
+		REQUIRE(back == v);
+	}
+}
+
+static void test_errors()
+{
+	std::vector<int32_t> v(257, 3);
+	oroch::integer_codec<int32_t>::metadata meta;
+	bool thrown = false;
+	try {
+		oroch::integer_codec<int32_t>::select(meta, v.begin(), v.end());
+	} catch (const std::length_error &) {
+		thrown = true;
+	}
+	REQUIRE(thrown);
+	// Metadata that select() would not produce for the values is refused.
+	std::vector<int32_t> w = {1, 2, 3, 4, 5, 6, 7, 8};
+	oroch::integer_codec<int32_t>::select(meta, w.begin(), w.end());
+	meta.value_desc.encoding = oroch::normal;
+	uint8_t buf[256];
+	oroch::dst_bytes_t d = buf;
+	thrown = false;
+	try {
+		oroch::integer_codec<int32_t>::encode(d, w.begin(), w.end(), meta);
+	} catch (const std::logic_error &) {
+		thrown = true;
+	}
+	REQUIRE(thrown);
+	// Empty input.
+	oroch::integer_codec<int32_t>::select(meta, w.begin(), w.begin());
+	REQUIRE(meta.value_desc.encoding == oroch::normal);
+	REQUIRE(meta.dataspace() == 0 && meta.metaspace() == 1);
+}
+
+template <typename T>
+static void run_type(const char *name)
+{
+	test_stats_select_group<T>();
+	test_sequences<T>();
+	test_blocks<T>();
+	std::printf("%-8s ok so far: %d checks, %d failed\n", name, g_checks, g_failed);
+	std::fflush(stdout);
+}
+
+int main()
+{
+	oroch::hip::check(oroch_hip_init(0), "oroch_hip_init");
+	test_bitpfr_value_codec();
+	test_bitpfr_reference_case<uint32_t>(1000);
+	test_bitpfr_reference_case<int32_t>(-1000);
+	test_bitpfr_two_calls();
+	test_group_reference_case();
+	test_errors();
+	run_type<int8_t>("int8");
+	run_type<uint8_t>("uint8");
+	run_type<int16_t>("int16");
+	run_type<uint16_t>("uint16");
+	run_type<int32_t>("int32");
+	run_type<uint32_t>("uint32");
+	run_type<int64_t>("int64");
+	run_type<uint64_t>("uint64");
+	std::printf("%d checks, %d failed\n", g_checks, g_failed);
+	return g_failed ? 1 : 0;
+}

@@ -275,3 +275,20 @@ def test_two_pass_path_matches_single_pass(hip, oracle):
     assert np.array_equal(host(o1), host(o2)) and np.array_equal(host(s1), host(s2))
     exp, exp_offs = oracle.blocks_encode(a, 256, 16)
     assert np.array_equal(host(s1), exp) and np.array_equal(host(o1).astype(np.uint64), exp_offs)
+
+
+@pytest.mark.parametrize("dt", dg.DTYPES)
+def test_block_statistics_against_oracle(hip, oracle, dt):
+    rng = np.random.default_rng(77 + dg.DTYPES.index(dt))
+    W = np.dtype(dt).itemsize * 8
+    blocks = [dg.fuzz_block(rng, dt, 256) for _ in range(200)]
+    blocks.append(dg.fuzz_block(rng, dt, int(rng.integers(1, 256))))
+    a = np.concatenate(blocks)
+    st = hip.group_stats(dev(a))
+    assert len(st) == len(blocks)
+    for b, blk in enumerate(blocks):
+        mn, mx, hist = oracle.stats(blk)
+        assert int(st[b]["nvalues"]) == blk.size
+        assert int(st[b]["min"]) == mn and int(st[b]["max"]) == mx, (b, st[b], mn, mx)
+        assert np.array_equal(st[b]["histogram"][:W + 1].astype(np.uint64), hist[:W + 1]), b
+        assert not st[b]["histogram"][W + 1:].any()
