@@ -105,14 +105,50 @@ def cpu_baseline(log2n, seed):
                       "(encode %.2fs, decode %.2fs)" % (log2n, t1 - t0, t2 - t1)}
 
 
+def end_to_end(x_dev, log2n):
+    """Host buffer -> pinned staging -> device encode -> host stream, and back."""
+    import ctypes as C
+
+    import oroch_amd
+
+    n = 1 << log2n
+    a = x_dev[:n].cpu().numpy()
+    code = oroch_amd.dtype_code(a.dtype)
+    lib = oroch_amd.lib
+    bound = lib.oroch_group_bound(code, n)
+    out = np.zeros(bound, np.uint8)
+    offs = np.zeros((n + 255) // 256 + 1, np.uint64)
+    back = np.zeros(n, a.dtype)
+    total = C.c_uint64(0)
+    best = [None, None]
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = lib.oroch_group_encode_host(code, a.ctypes.data, n, out.ctypes.data, bound,
+                                         offs.ctypes.data, C.byref(total))
+        t1 = time.perf_counter()
+        rc = rc or lib.oroch_group_decode_host(code, out.ctypes.data, offs.ctypes.data, n,
+                                               back.ctypes.data)
+        t2 = time.perf_counter()
+        if rc:
+            raise SystemExit("host entry points failed: %d" % rc)
+        best[0] = min(best[0] or 1e9, t1 - t0)
+        best[1] = min(best[1] or 1e9, t2 - t1)
+    if not np.array_equal(back, a):
+        raise SystemExit("host round trip mismatch")
+    return {"values": n, "encode_GBps": a.nbytes / best[0] / 1e9, "decode_GBps": a.nbytes / best[1] / 1e9,
+            "note": "pageable host buffers in and out, staged through pinned memory; includes "
+                    "H2D and D2H copies and device allocation; best of 3"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=30, help="log2 of values per GPU")
-    ap.add_argument("--cpu-log2n", type=int, default=25)
+    ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,7 +266,9 @@ def main():
                                          "frac": (raw + total) / (kern.get("decode", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "shard_bytes": counts,
         }
-        if not args.no_cpu_baseline and world >= 1:
+        if world == 1 and not args.no_end_to_end:
+            line["end_to_end"] = end_to_end(x, min(args.log2n, 27))
+        if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed)
         print(json.dumps(line))
     if world > 1:

@@ -39,6 +39,11 @@ public:
 	{
 		basic_codec::decode(dst, end, src, params.nbits, params);
 	}
+	// bitfor.h:71-74.
+	static original_t fetch(src_bytes_t src, size_t index, const parameters &params)
+	{
+		return basic_codec::fetch(src, index, params.nbits, params);
+	}
 };
 
 } // namespace oroch

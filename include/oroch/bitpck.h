@@ -64,6 +64,66 @@ public:
 		return block_size * block_number(nvalues, nbits);
 	}
 
+	// bitpck.h:73-128: one 16-byte block from at most capacity(nbits)
+	// values; src and dst advance.
+	template <typename Iter>
+	static void block_encode(dst_bytes_t &dst, Iter &src, Iter const end, const size_t nbits,
+				 value_codec &vcodec)
+	{
+		const size_t c = capacity(nbits);
+		std::vector<T> in;
+		for (; src != end && in.size() < c; ++src)
+			in.push_back(static_cast<T>(*src));
+		if (in.empty()) {
+			std::fill_n(dst, block_size, byte_t(0));
+		} else {
+			using kind = detail::value_codec_kind<T, V>;
+			hip::check(oroch_pack_host(hip::dtype_of<T>(), kind::kind, in.data(), in.size(),
+						   kind::origin(vcodec), unsigned(nbits), dst),
+				   "bitpck_codec::block_encode");
+		}
+		dst += block_size;
+	}
+
+	// bitpck.h:130-169: a block that may hold fewer values than its capacity.
+	template <typename Iter>
+	static void block_decode(Iter dst, Iter const end, src_bytes_t &src, const size_t nbits,
+				 value_codec &vcodec)
+	{
+		const size_t n = std::min(size_t(std::distance(dst, end)), capacity(nbits));
+		src_bytes_t s = src;
+		if (n)
+			decode(dst, dst + n, s, nbits, vcodec);
+		src += block_size;
+	}
+
+	// bitpck.h:171-201: a full block.
+	template <typename Iter>
+	static void block_decode(Iter dst, src_bytes_t &src, const size_t nbits, value_codec &vcodec)
+	{
+		src_bytes_t s = src;
+		decode(dst, dst + capacity(nbits), s, nbits, vcodec);
+		src += block_size;
+	}
+
+	// bitpck.h:203-225: value `index` of one block.
+	static original_t block_fetch(src_bytes_t src, const size_t index, const size_t nbits,
+				      value_codec &vcodec)
+	{
+		std::vector<T> out(index + 1);
+		src_bytes_t s = src;
+		decode(out.begin(), out.end(), s, nbits, vcodec);
+		return out[index];
+	}
+
+	// bitpck.h:258-266: value `index` of a packed sequence.
+	static original_t fetch(src_bytes_t src, const size_t index, const size_t nbits,
+				value_codec vcodec = value_codec())
+	{
+		const size_t c = capacity(nbits);
+		return block_fetch(src + (index / c) * block_size, index % c, nbits, vcodec);
+	}
+
 	// bitpck.h:227-240.  dst advances by space(n, nbits).
 	template <typename Iter>
 	static void encode(dst_bytes_t &dst, Iter src, Iter const end, size_t nbits,

@@ -223,6 +223,61 @@ static void test_sequences()
 	}
 }
 
+// Block-level members of bitpck_codec (bitpck.h:73-225, 258-266), in the shape
+// of tests/unit/bitblk.cc: values wider than nbits are truncated by the mask.
+static void test_bitpck_blocks()
+{
+	using codec = oroch::bitpck_codec<uint32_t>;
+	for (size_t nbits : {1, 5, 13, 31, 32}) {
+		const size_t c = codec::capacity(nbits);
+		std::vector<uint32_t> v(c + 3);
+		for (auto &x : v)
+			x = uint32_t(rnd());
+		std::vector<uint8_t> bytes(32), want(32);
+		oroch::zigzag_codec<uint32_t> vc;
+		oroch::dst_bytes_t d = bytes.data();
+		auto it = v.begin();
+		codec::block_encode(d, it, v.end(), nbits, vc);
+		REQUIRE(size_t(it - v.begin()) == c);
+		codec::block_encode(d, it, v.end(), nbits, vc);
+		REQUIRE(it == v.end() && d == bytes.data() + 32);
+		orc_bitpck_encode(5, v.data(), v.size(), unsigned(nbits), want.data());
+		REQUIRE(bytes == want);
+		const uint32_t mask = nbits == 32 ? ~0u : (1u << nbits) - 1;
+		std::vector<uint32_t> back(c + 3);
+		oroch::src_bytes_t s = bytes.data();
+		codec::block_decode(back.begin(), s, nbits, vc);
+		codec::block_decode(back.begin() + c, back.end(), s, nbits, vc);
+		REQUIRE(s == bytes.data() + 32);
+		for (size_t i = 0; i < v.size(); i++)
+			REQUIRE(back[i] == (v[i] & mask));
+		REQUIRE(codec::fetch(bytes.data(), c + 1, nbits) == (v[c + 1] & mask));
+		REQUIRE(codec::block_fetch(bytes.data(), c - 1, nbits, vc) == (v[c - 1] & mask));
+	}
+	// A 64-bit codec fed 32-bit data, tests/unit/bitpck.cc:59-68.
+	std::array<uint32_t, 100> small;
+	for (auto &x : small)
+		x = uint32_t(rnd() & 0x1ffff);
+	using wide = oroch::bitpck_codec<uint64_t>;
+	std::vector<uint8_t> bytes(wide::space(small.size(), 17));
+	oroch::dst_bytes_t d = bytes.data();
+	wide::encode(d, small.begin(), small.end(), 17);
+	std::array<uint32_t, 100> back;
+	oroch::src_bytes_t s = bytes.data();
+	wide::decode(back.begin(), back.end(), s, 17);
+	REQUIRE(back == small);
+	using bfor = oroch::bitfor_codec<int16_t>;
+	std::array<int16_t, 40> w;
+	for (size_t i = 0; i < w.size(); i++)
+		w[i] = int16_t(-300 + int(i) * 3);
+	bfor::parameters params(-300, 7);
+	std::vector<uint8_t> fb(bfor::space(w.size(), 7));
+	d = fb.data();
+	bfor::encode(d, w.begin(), w.end(), params);
+	for (size_t i = 0; i < w.size(); i++)
+		REQUIRE(bfor::fetch(fb.data(), i, params) == w[i]);
+}
+
 // tests/unit/bitpfr.cc:13-30.
 static void test_bitpfr_value_codec()
 {
@@ -369,6 +424,7 @@ static void run_type(const char *name)
 int main()
 {
 	oroch::hip::check(oroch_hip_init(0), "oroch_hip_init");
+	test_bitpck_blocks();
 	test_bitpfr_value_codec();
 	test_bitpfr_reference_case<uint32_t>(1000);
 	test_bitpfr_reference_case<int32_t>(-1000);
