@@ -1,0 +1,426 @@
+// decode_quad.hpp -- the decoder's fast path: four consecutive blocks per
+// wavefront, sixteen lanes per block.
+//
+// With one block per wavefront most of the per-block work (header parsing,
+// exception lists) is wave-uniform and ends up on the scalar unit, and the
+// bit-field extraction keeps only as many lanes busy as the block has packed
+// 16-byte words (22 of 64 at 10 bits).  Here four blocks share a wavefront:
+// each 16-lane group parses its own block's header and exception lists in
+// vector registers (DPP row operations stay inside a group), and the packed
+// words of all four blocks are spread over all 64 lanes.  The path covers what
+// the selector produces for ordinary numeric data -- bitpck, bitfor and bitpfr
+// blocks of one common width, exception lists coded as varints -- and anything
+// else (other encodings, mixed widths, bit-packed or long lists, a short last
+// block) goes block by block through decode_block, from the same staged bytes.
+//
+// Included by group.hip after decode_block; 8-, 16- and 32-bit element types.
+#pragma once
+
+namespace oroch_hip {
+
+constexpr int QUAD = 4;            // blocks per wavefront step
+constexpr int GROUP = WAVE / QUAD; // lanes per block
+constexpr int SLOT_STRIDE = BLOCK + FIELDS_PAD;
+constexpr int LIST_BYTES = GROUP * 4; // exception-list bytes a group looks at
+constexpr int ENDS = 48;              // varint end positions per group (+ dump slots)
+constexpr uint32_t QUAD_MAX_EXC = 16; // one exception per lane of a group
+
+// Inclusive prefix sum within each row of 16 lanes.
+__device__ __forceinline__ uint32_t row_scan_sum(uint32_t x)
+{
+	x += dpp_mov<0x111>(0u, x);
+	x += dpp_mov<0x112>(0u, x);
+	x += dpp_mov<0x114>(0u, x);
+	x += dpp_mov<0x118>(0u, x);
+	return x;
+}
+
+__device__ __forceinline__ uint32_t lane_gather(uint32_t x, int src_lane)
+{
+	return uint32_t(__builtin_amdgcn_ds_bpermute(src_lane * 4, int(x)));
+}
+
+// The 7-bit groups of the four bytes in lo up to and including the first byte
+// without a continuation bit (varint.h:85-115); *more is set when all four
+// bytes continue, i.e. a fifth byte belongs to the value.
+__device__ __forceinline__ uint32_t varint4(uint32_t lo, bool *more, uint32_t *nbytes)
+{
+	const uint32_t t = ~lo & 0x80808080u;
+	const uint32_t keep = t ^ (t - 1u); // bits up to the terminator's top bit; all ones if none
+	lo &= keep;
+	*more = t == 0;
+	*nbytes = t ? (uint32_t(__builtin_ctz(t)) >> 3) + 1u : 5u;
+	return (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) | ((lo >> 2) & 0x1fc000u) | ((lo >> 3) & 0xfe00000u);
+}
+
+// The varint (at most five bytes) that starts at byte `at` of an LDS image.
+__device__ __forceinline__ uint32_t varint_at(const uint32_t *img, uint32_t at)
+{
+	const uint32_t d = at >> 2, s = (at & 3u) * 8u;
+	const uint32_t a = img[d], b = img[d + 1];
+	const uint32_t lo = __builtin_amdgcn_alignbit(b, a, s);
+	bool more;
+	uint32_t nbytes;
+	uint32_t v = varint4(lo, &more, &nbytes);
+	if (more) {
+		// byte 4 of the value sits 32 bits above `at`
+		const uint32_t c = img[d + 2];
+		const uint32_t hi = __builtin_amdgcn_alignbit(c, b, s);
+		v |= (hi & 0x0fu) << 28;
+	}
+	return v;
+}
+
+// Per-block metadata as each lane of the block's group sees it.
+struct quad_header
+{
+	uint32_t enc, nb, origin, nout, inb, vnb, doff;
+	bool plain; // parsed completely by the short-form rules below
+};
+
+// integer_codec.h:153-214 in vector registers, for the three bit-packed
+// encodings of element types up to 32 bits: [enc][origin varint <= 5 bytes]
+// [nbits][noutliers varint <= 2 bytes][index nbits][value nbits].
+template <typename E>
+__device__ __forceinline__ quad_header parse_header(const uint4 h)
+{
+	quad_header r;
+	r.enc = h.x & 0xffu;
+	const bool has_origin = r.enc == OROCH_BITFOR || r.enc == OROCH_BITPFR;
+	// bytes 1..12 of the header
+	const uint32_t y0 = __builtin_amdgcn_alignbyte(h.y, h.x, 1);
+	const uint32_t y1 = __builtin_amdgcn_alignbyte(h.z, h.y, 1);
+	const uint32_t y2 = __builtin_amdgcn_alignbyte(h.w, h.z, 1);
+	bool more;
+	uint32_t olen;
+	uint32_t zo = varint4(y0, &more, &olen);
+	if (more)
+		zo |= (y1 & 0x0fu) << 28;
+	if (!has_origin) {
+		zo = 0;
+		olen = 0;
+	}
+	r.origin = unzz<E>(zo & E::MASK);
+	// the bytes after the origin
+	const bool far = olen >= 4;
+	const uint32_t a = far ? y1 : y0, b = far ? y2 : y1, c = far ? 0u : y2;
+	const uint32_t sh = (olen & 3u) * 8u;
+	const uint32_t z0 = __builtin_amdgcn_alignbit(b, a, sh);
+	const uint32_t z1 = __builtin_amdgcn_alignbit(c, b, sh);
+	r.nb = z0 & 0xffu;
+	const uint32_t b1 = (z0 >> 8) & 0xffu, b2 = (z0 >> 16) & 0xffu;
+	const bool two = (b1 & 0x80u) != 0;
+	r.plain = r.enc == OROCH_BITPCK || has_origin;
+	uint32_t p = 1u + olen + 1u;
+	r.nout = 0;
+	r.inb = 0;
+	r.vnb = 0;
+	if (r.enc == OROCH_BITPFR) {
+		r.nout = (b1 & 0x7fu) | (two ? (b2 & 0x7fu) << 7 : 0u);
+		r.inb = two ? z0 >> 24 : b2;
+		r.vnb = two ? z1 & 0xffu : z0 >> 24;
+		r.plain = r.plain && !(two && (b2 & 0x80u));
+		p += two ? 4u : 3u;
+	}
+	r.doff = (p + 7u) & ~7u; // integer_group.h:70-72
+	return r;
+}
+
+// Lane p, p + 64, ... unpacks packed word p of the quad: word j of block gp.
+template <typename E, int NB>
+__device__ __forceinline__ void unpack_quad_words(const uint8_t *qb, uint32_t data_at, int lane,
+						  typename E::C *slots)
+{
+	using C = typename E::C;
+	constexpr uint32_t NBLK = (BLOCK + 128 / NB - 1) / (128 / NB); // packed words per block
+	constexpr uint32_t P = QUAD * NBLK;
+#pragma unroll
+	for (uint32_t r = 0; r < (P + WAVE - 1) / WAVE; r++) {
+		const uint32_t p = uint32_t(lane) + r * WAVE;
+		const uint32_t gp = (p >= NBLK ? 1u : 0u) + (p >= 2 * NBLK ? 1u : 0u) + (p >= 3 * NBLK ? 1u : 0u);
+		const uint32_t j = p - gp * NBLK;
+		// data_at of block gp lives in the lanes of group gp
+		const uint32_t at = lane_gather(data_at, int(gp * GROUP));
+		if (p < P) {
+			const uint2 *q = reinterpret_cast<const uint2 *>(qb + at) + j * 2;
+			const uint2 x = q[0], y = q[1];
+			const uint32_t w[4] = {x.x, x.y, y.x, y.y};
+			unpack_fields<C, NB>(w, slots + gp * SLOT_STRIDE, int(j));
+		}
+	}
+}
+
+template <typename E, int LO, int HI>
+__device__ __forceinline__ void unpack_quad_dispatch(uint32_t nb, const uint8_t *qb, uint32_t data_at,
+						     int lane, typename E::C *slots)
+{
+	if constexpr (LO == HI) {
+		unpack_quad_words<E, LO>(qb, data_at, lane, slots);
+	} else {
+		constexpr int MID = (LO + HI) / 2;
+		if (nb <= uint32_t(MID))
+			unpack_quad_dispatch<E, LO, MID>(nb, qb, data_at, lane, slots);
+		else
+			unpack_quad_dispatch<E, MID + 1, HI>(nb, qb, data_at, lane, slots);
+	}
+}
+
+// Tries the four-block path on the bytes staged in qbuf (block g at byte
+// rel[g], rel in lanes 0..4).  Returns false, having changed nothing that
+// matters, if the quad does not qualify.
+template <typename E>
+__device__ __forceinline__ bool decode_quad_fast(const uint32_t *qbuf, uint32_t qbytes, uint32_t rel,
+						  int lane, typename E::C *slots, uint8_t *ends,
+						  const uint4 *wt, typename E::S *dst, size_t base)
+{
+	using C = typename E::C;
+	static_assert(sizeof(C) == 4, "element types up to 32 bits");
+	const uint8_t *qb = reinterpret_cast<const uint8_t *>(qbuf);
+	// Everything below that depends only on the lane number is the same for
+	// every quad; left alone, the compiler computes it all once, for every
+	// width, ahead of the quad loop and keeps it in registers (over 200 of
+	// them).  An opaque lane number makes it recompute the little it needs.
+	asm volatile("" : "+v"(lane));
+	const int g = lane / GROUP, sub = lane % GROUP;
+	const uint32_t r0 = lane_gather(rel, g), r1 = lane_gather(rel, g + 1);
+	const uint32_t len = r1 - r0;
+	const bool inside = r0 + 16u <= qbytes && r1 <= qbytes && r0 < r1;
+	const uint4 h = *reinterpret_cast<const uint4 *>(qb + (inside ? r0 : 0u));
+	const quad_header m = parse_header<E>(h);
+	const uint32_t nb = m.nb;
+	const bool width_ok = nb >= uint32_t(FIELDS_MIN_NB) && nb <= uint32_t(E::W);
+	const uint32_t pck = wt[width_ok ? nb : 1u].w; // bytes of the packed words of 256 values
+	const uint32_t list_at = m.doff + pck;
+	bool ok = inside && m.plain && width_ok && list_at <= len;
+	// Exception lists, integer_codec.h:583-609: gap-coded positions, then high
+	// parts, each either bit-packed or as varints.  One exception per lane
+	// and round; varints are located through a 64-byte window, which holds
+	// at least 16 of them.
+	const bool has_exc = m.enc == OROCH_BITPFR;
+	const uint4 iw = wt[m.inb && m.inb <= 32u ? m.inb : 1u], vw = wt[m.vnb && m.vnb <= 32u ? m.vnb : 1u];
+	const uint32_t ilen_pck = 16u * __umulhi(m.nout + iw.x - 1u, iw.y); // bitpck.h:61-71
+	const uint32_t scan_rel = list_at + (m.inb ? ilen_pck : 0u);        // where varints start
+	if (has_exc) {
+		ok = ok && m.nout >= 1 && m.nout <= uint32_t(BLOCK) && m.inb <= 32u && m.vnb <= uint32_t(E::W);
+		if (!m.inb || !m.vnb)
+			ok = ok && m.nout <= QUAD_MAX_EXC;
+		if (!m.vnb)
+			ok = ok && scan_rel <= len && len - scan_rel <= uint32_t(LIST_BYTES);
+		else
+			ok = ok && scan_rel + 16u <= len;
+	}
+	const uint32_t nb_u = uniform(nb);
+	ok = ok && nb == nb_u;
+	const uint64_t all = __ballot(ok);
+	if ((uint32_t(all) & uint32_t(all >> 32)) != 0xffffffffu)
+		return false;
+
+	unpack_quad_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, qb, r0 + m.doff, lane, slots);
+
+	if (__ballot(has_exc) != 0) {
+		const uint32_t lb = r0 + list_at;      // index list; a multiple of 8
+		const uint32_t sb = r0 + scan_rel;     // first varint, if any list has them
+		uint8_t *my_ends = ends + g * ENDS;
+		if (__ballot(has_exc && (!m.inb || !m.vnb)) != 0) {
+			// every lane looks at four bytes of the window and files the end
+			// position of each varint that ends there under the varint's number
+			const uint32_t w = qbuf[(sb >> 2) + uint32_t(sub)];
+			const uint32_t t = ~w & 0x80808080u;
+			const uint32_t cnt = uint32_t(__popc(t));
+			const uint32_t before = row_scan_sum(cnt) - cnt;
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const bool term = (t >> (8 * b + 7)) & 1u;
+				const uint32_t rank = before + uint32_t(__popc(t & ((1u << (8 * b + 7)) - 1u)));
+				const uint32_t slot = term && rank < 2 * QUAD_MAX_EXC ? rank + 1u : uint32_t(ENDS - 4 + b);
+				my_ends[slot] = uint8_t(4 * sub + b + 1);
+			}
+			wave_sync();
+		}
+		// where the value list starts when the index list is varints: after
+		// varint number nout - 1
+		const uint32_t vb = m.inb ? sb : sb + (has_exc && !m.inb ? my_ends[m.nout <= QUAD_MAX_EXC ? m.nout : 0u] : 0u);
+		const uint32_t voff = m.inb ? 0u : m.nout; // number of the first value varint
+		C *mine = slots + g * SLOT_STRIDE;
+		const uint32_t rounds = uniform(wave_max(has_exc ? (m.nout + GROUP - 1u) / GROUP : 0u));
+		uint32_t carry = 0;
+		for (uint32_t r = 0; r < rounds; r++) {
+			const uint32_t e = uint32_t(sub) + r * GROUP;
+			const bool active = has_exc && e < m.nout;
+			uint32_t gap = 0, hi = 0;
+			if (__ballot(active && m.inb) != 0) {
+				const uint32_t bk = __umulhi(e, iw.y);
+				gap = lds_get_bits32(qbuf, lb * 8u + bk * 128u + (e - bk * iw.x) * m.inb, m.inb ? m.inb : 1u);
+			}
+			if (__ballot(active && !m.inb) != 0) {
+				const uint32_t is = active && e && !m.inb ? my_ends[e] : 0u;
+				const uint32_t x = varint_at(qbuf, sb + is);
+				gap = m.inb ? gap : x;
+			}
+			if (__ballot(active && m.vnb) != 0) {
+				const uint32_t bk = __umulhi(e, vw.y);
+				hi = lds_get_bits32(qbuf, vb * 8u + bk * 128u + (e - bk * vw.x) * m.vnb, m.vnb ? m.vnb : 1u);
+			}
+			if (__ballot(active && !m.vnb) != 0) {
+				const uint32_t vs = active && !m.vnb && voff + e ? my_ends[voff + e] : 0u;
+				const uint32_t x = varint_at(qbuf, sb + vs);
+				hi = m.vnb ? hi : x;
+			}
+			// positions: running sum of gap + 1 (offset.h:62-67)
+			const uint32_t incl = row_scan_sum(active ? gap + 1u : 0u) + carry;
+			carry = lane_gather(incl, g * GROUP + GROUP - 1);
+			const uint32_t pos = incl - 1u;
+			const bool hit = active && pos < uint32_t(BLOCK);
+			// lanes with nothing to patch OR zero into a spare slot
+			atomicOr(&mine[hit ? pos : uint32_t(SLOT_STRIDE - 1)], hit ? C(hi << nb_u) & E::MASK : C(0));
+		}
+	}
+	wave_sync();
+
+	// every lane picks up four values of each block; origin and encoding of
+	// block s come from the first lane of its group
+#pragma unroll
+	for (int s = 0; s < QUAD; s++) {
+		const uint32_t origin = read_lane(m.origin, s * GROUP);
+		const uint32_t enc = read_lane(m.enc, s * GROUP);
+		const uint4 q = *reinterpret_cast<const uint4 *>(&slots[s * SLOT_STRIDE + lane * VPL]);
+		C v[VPL] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+		for (int i = 0; i < VPL; i++)
+			v[i] = enc == OROCH_BITPCK ? unzz<E>(v[i] & E::MASK) : C((v[i] + origin) & E::MASK);
+		store_block<E>(dst, base + size_t(s) * BLOCK, BLOCK, lane, v);
+	}
+	return true;
+}
+
+#ifdef OROCH_EXP_COUNT
+__device__ unsigned long long g_quad_count[2];
+} extern "C" int oroch_debug_quad_count(unsigned long long *out)
+{
+	return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(oroch_hip::g_quad_count), 16));
+}
+namespace oroch_hip {
+#endif
+
+// Persistent wavefronts over quads of blocks; offsets are fetched two quads
+// ahead and the quad's bytes one quad ahead (the first QPRE KiB of them, in
+// registers), so the dependent latencies overlap with decoding.
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_t *__restrict__ src,
+								      const uint64_t *__restrict__ offsets,
+								      size_t n, size_t nblocks,
+								      typename E::S *__restrict__ dst)
+{
+	using C = typename E::C;
+	constexpr uint32_t IMG = uint32_t(image_bytes<E>() - 16); // longest block image
+	constexpr uint32_t QBYTES = QUAD * IMG;
+	constexpr int NCH = int((QBYTES + 1023) / 1024);
+	constexpr int NPRE = NCH < 3 ? NCH : 3;
+	__shared__ __attribute__((aligned(16))) uint32_t qbufs[WAVES_PER_WG][QBYTES / 4 + 24];
+	__shared__ __attribute__((aligned(16))) C slotss[WAVES_PER_WG][QUAD * SLOT_STRIDE];
+	__shared__ __attribute__((aligned(16))) uint8_t endss[WAVES_PER_WG][QUAD * ENDS];
+	__shared__ uint4 wt[65];
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	load_width_table(wt);
+	uint32_t *qbuf = qbufs[wave];
+	uint8_t *qb = reinterpret_cast<uint8_t *>(qbuf);
+	C *slots = slotss[wave];
+	const size_t nquads = (nblocks + QUAD - 1) / QUAD;
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
+
+	// lanes 0..4 hold the offsets of the quad's blocks and its end
+	auto extent = [&](size_t q, uint64_t &o) {
+		o = 0;
+		if (q < nquads) {
+			size_t i = q * QUAD + size_t(lane < QUAD ? lane : QUAD);
+			if (i > nblocks)
+				i = nblocks;
+			o = __builtin_nontemporal_load(offsets + i);
+		}
+	};
+	auto resolve = [&](uint64_t o, uint64_t &start, uint32_t &rel, uint32_t &total) {
+		start = read_lane(o, 0);
+		rel = clamp_u64(o - start, QBYTES);
+		total = read_lane(rel, QUAD);
+	};
+	auto fetch = [&](uint64_t start, uint32_t total, uint4 (&im)[NPRE]) {
+#pragma unroll
+		for (int c = 0; c < NPRE; c++) {
+			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+			im[c] = make_uint4(0, 0, 0, 0);
+			if (o < total)
+				im[c] = *reinterpret_cast<const uint4 *>(src + start + o);
+		}
+	};
+
+	size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave;
+	uint64_t o0, o1, o2, start0, start1;
+	uint32_t rel0, rel1, total0, total1;
+	uint4 im0[NPRE], im1[NPRE];
+	extent(q, o0);
+	extent(q + stride, o1);
+	resolve(o0, start0, rel0, total0);
+	fetch(start0, total0, im0);
+	for (; q < nquads; q += stride) {
+		extent(q + 2 * stride, o2);
+		resolve(o1, start1, rel1, total1);
+		fetch(start1, total1, im1);
+
+#pragma unroll
+		for (int c = 0; c < NPRE; c++) {
+			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+			if (o < total0)
+				*reinterpret_cast<uint4 *>(qb + o) = im0[c];
+		}
+		// a quad longer than what was fetched ahead: the rest, now
+		for (uint32_t o = uint32_t(NPRE) * 1024u + uint32_t(lane) * 16u; o < total0; o += 1024u)
+			*reinterpret_cast<uint4 *>(qb + o) = *reinterpret_cast<const uint4 *>(src + start0 + o);
+		wave_sync();
+
+		const size_t blk0 = q * QUAD;
+		const size_t base = blk0 * BLOCK;
+		bool done = false;
+#ifndef OROCH_EXP_NOFAST
+		if (blk0 + QUAD <= nblocks && base + size_t(QUAD) * BLOCK <= n)
+#else
+		if (false)
+#endif
+			done = decode_quad_fast<E>(qbuf, total0, rel0, lane, slots, endss[wave], wt, dst, base);
+#ifdef OROCH_EXP_COUNT
+		if (lane == 0)
+			atomicAdd(&g_quad_count[done ? 0 : 1], 1ull);
+#endif
+#ifdef OROCH_EXP_NOSLOW
+		done = true;
+#endif
+		if (!done) {
+			// block by block, from the same staged bytes
+			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
+				const uint32_t at = read_lane(rel0, b), end = read_lane(rel0, b + 1);
+				const uint32_t len = end > at ? end - at : 0u;
+				const int nv = block_count(n, blk0 + size_t(b));
+				C v[VPL];
+				uint32_t *img = qbuf + (at >> 2);
+				C *val = slots, *hv = slots + SLOT_STRIDE;
+				uint32_t *gp = reinterpret_cast<uint32_t *>(slots + 2 * SLOT_STRIDE);
+				if (nv == BLOCK)
+					decode_block<E, true>(img, len, nv, lane, val, hv, gp, wt, v);
+				else
+					decode_block<E, false>(img, len, nv, lane, val, hv, gp, wt, v);
+				store_block<E>(dst, base + size_t(b) * BLOCK, nv, lane, v);
+				wave_sync();
+			}
+		}
+		wave_sync();
+
+		o1 = o2;
+		start0 = start1;
+		rel0 = rel1;
+		total0 = total1;
+#pragma unroll
+		for (int c = 0; c < NPRE; c++)
+			im0[c] = im1[c];
+	}
+}
+
+} // namespace oroch_hip

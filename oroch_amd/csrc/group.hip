@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "bitfield.hpp"
 #include "scan.hpp"
 
 namespace oroch_hip {
@@ -1217,7 +1218,7 @@ __device__ __forceinline__ uint64_t hdr_varint(uint64_t h0, uint64_t h1, uint32_
 // Decodes the block whose image (len bytes) sits in `img`.  FULL: 256 values.
 template <typename E, bool FULL>
 __device__ void decode_block(uint32_t *img, uint32_t len, int nv, int lane, typename E::C *val,
-			     uint32_t *gp, const uint4 *wt, typename E::C (&v)[VPL])
+			     typename E::C *hv, uint32_t *gp, const uint4 *wt, typename E::C (&v)[VPL])
 {
 	using C = typename E::C;
 	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
@@ -1266,101 +1267,106 @@ __device__ void decode_block(uint32_t *img, uint32_t len, int nv, int lane, type
 			if (FULL || lane * VPL + s < nv)
 				v[s] = raw[lane * VPL + s];
 	} else if ((enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) && sane) {
-		// bitpck.h:171-201 as a bit-field read
-		const uint4 we = wt[nb];
-		const uint32_t cap = uniform(we.x), m16 = uniform(we.z);
-		C u[VPL];
+		// bitpck.h:171-201.  Unpacked values go to val[] (one slot per value),
+		// exceptions are OR-ed into their slots there, then every lane picks up
+		// its four values.
+		if (nb >= uint32_t(FIELDS_MIN_NB)) {
+			// lane j unpacks packed block j with compile-time field positions
+			const uint32_t nblk = pck_space(wt, uint32_t(nv), nb) >> 4;
+			// (widths above 32 bits have more than 64 packed blocks)
+#ifdef OROCH_EXP_NOUNPACK
+			for (uint32_t j = uint32_t(lane); j < 0; j += WAVE) {
+#else
+			for (uint32_t j = uint32_t(lane); j < nblk; j += WAVE) {
+#endif
+				const uint2 *q = reinterpret_cast<const uint2 *>(img8 + doff) + j * 2;
+				const uint2 a = q[0], b = q[1];
+				const uint32_t w[4] = {a.x, a.y, b.x, b.y};
+				unpack_dispatch<C, FIELDS_MIN_NB, E::W>(nb, w, val, int(j));
+			}
+		} else {
+			// narrow fields: one value per lane and step
+			const uint4 we = wt[nb];
+			const uint32_t cap = uniform(we.x), m16 = uniform(we.z);
 #pragma unroll
-		for (int s = 0; s < VPL; s++) {
-			const uint32_t pos = uint32_t(lane * VPL + s);
-			u[s] = 0;
-			if (FULL || pos < uint32_t(nv)) {
+			for (int s = 0; s < VPL; s++) {
+				const uint32_t pos = uint32_t(lane * VPL + s);
 				const uint32_t blkn = (pos * m16) >> 16;
 				const uint32_t k = pos - blkn * cap;
-				u[s] = lds_get_bits<C>(img, doff * 8u + blkn * 128u + k * nb, nb) & E::MASK;
+				C x = 0;
+				if (FULL || pos < uint32_t(nv))
+					x = lds_get_bits<C>(img, doff * 8u + blkn * 128u + k * nb, nb) & E::MASK;
+				val[pos] = x;
 			}
 		}
+		wave_sync();
+#ifdef OROCH_EXP_NOEXC
+		if (false) {
+#else
 		if (enc == OROCH_BITPFR && nout > 0 && nout <= uint32_t(nv) && vnb <= uint32_t(E::W) &&
 		    inb <= 64) {
+#endif
 			// integer_codec.h:583-609, bitpfr.h:114-124
 			const uint32_t ibase = doff + pck_space(wt, uint32_t(nv), nb);
-			// list slots are filled by OR, so the ones in use start at zero
-#ifdef OROCH_EXP_FULLZERO
-			for (uint32_t i = uint32_t(lane); i < BLOCK; i += WAVE) {
-#else
-			for (uint32_t i = uint32_t(lane); i < nout; i += WAVE) {
-#endif
-				val[i] = 0;
-				gp[i] = 0;
-			}
-			wave_sync();
-			uint32_t ilen;
-			if (inb) {
-				const uint32_t icap = uniform(wt[inb].x), imagic = uniform(wt[inb].y);
-				for (uint32_t e = uint32_t(lane); e < nout; e += WAVE) {
-					const uint32_t bk = __umulhi(e, imagic);
-					gp[e] = uint32_t(lds_get_bits64(img, ibase * 8u + bk * 128u + (e - bk * icap) * inb,
-								       inb));
+			// varint lists are assembled by OR into zeroed LDS slots
+			if (!inb || !vnb) {
+				for (uint32_t i = uint32_t(lane); i < nout; i += WAVE) {
+					hv[i] = 0;
+					gp[i] = 0;
 				}
-				ilen = pck_space(wt, nout, inb);
 				wave_sync();
-			} else {
-				ilen = varint_list_decode<uint32_t>(img8, ibase, len, nout, gp, lane);
 			}
+			const uint32_t ilen = inb ? pck_space(wt, nout, inb)
+						  : varint_list_decode<uint32_t>(img8, ibase, len, nout, gp, lane);
 			const uint32_t vbase = ibase + ilen;
-			if (vnb) {
-				const uint32_t vcap = uniform(wt[vnb].x), vmagic = uniform(wt[vnb].y);
-				for (uint32_t e = uint32_t(lane); e < nout; e += WAVE) {
-					const uint32_t bk = __umulhi(e, vmagic);
-					val[e] = lds_get_bits<C>(img, vbase * 8u + bk * 128u + (e - bk * vcap) * vnb, vnb);
-				}
-				wave_sync();
-			} else {
-				varint_list_decode<C>(img8, vbase, len, nout, val, lane);
-			}
-			// positions: running sum of gap + 1 (offset.h:62-67); then every
-			// exception hands its high part to the lane owning the position
+			if (!vnb)
+				varint_list_decode<C>(img8, vbase, len, nout, hv, lane);
+			const uint4 iw = wt[inb ? inb : 1u], vw = wt[vnb ? vnb : 1u];
+			const uint32_t icap = uniform(iw.x), imagic = uniform(iw.y);
+			const uint32_t vcap = uniform(vw.x), vmagic = uniform(vw.y);
+			// positions: running sum of gap + 1 (offset.h:62-67); every
+			// exception ORs its high part into the slot of its position
 			uint32_t carry = 0;
-			C hi[VPL];
-			uint32_t epos[VPL];
 #pragma unroll
 			for (int it = 0; it < VPL; it++) {
-				hi[it] = 0;
-				epos[it] = ~0u;
 				if (uint32_t(it * WAVE) < nout) {
 					const uint32_t e = uint32_t(it * WAVE + lane);
-					const uint32_t step = e < nout ? gp[e] + 1u : 0u;
+					uint32_t step = 0;
+					if (e < nout) {
+						if (inb) {
+							const uint32_t bk = __umulhi(e, imagic);
+							step = uint32_t(lds_get_bits64(img, ibase * 8u + bk * 128u +
+												    (e - bk * icap) * inb, inb));
+						} else {
+							step = gp[e];
+						}
+						step += 1u;
+					}
 					const uint32_t incl = wave_scan_sum(step, lane) + carry;
 					carry = read_lane(incl, WAVE - 1);
-					epos[it] = e < nout ? incl - 1u : ~0u;
-					hi[it] = e < nout ? val[e] : C(0);
+					if (e < nout && incl - 1u < uint32_t(BLOCK)) {
+						C hi;
+						if (vnb) {
+							const uint32_t bk = __umulhi(e, vmagic);
+							hi = lds_get_bits<C>(img, vbase * 8u + bk * 128u + (e - bk * vcap) * vnb,
+									     vnb);
+						} else {
+							hi = hv[e];
+						}
+						val[incl - 1u] |= C(hi << nb) & E::MASK;
+					}
 				}
 			}
-#ifdef OROCH_DEBUG_DECODE2
-			if (lane == 0 && g_dbg) {
-				g_dbg[0] = 0xabcd; g_dbg[1] = uint32_t(nv); g_dbg[2] = nb; g_dbg[3] = doff; g_dbg[4] = nout;
-				g_dbg[5] = inb; g_dbg[6] = vnb; g_dbg[7] = ibase; g_dbg[8] = ilen; g_dbg[9] = vbase;
-				g_dbg[10] = len; g_dbg[11] = gp[0]; g_dbg[12] = uint32_t(val[0]); g_dbg[13] = epos[0];
-				g_dbg[14] = uint32_t(hi[0]); g_dbg[15] = uint32_t(FULL);
-			}
-#endif
 			wave_sync();
-			// the value scratch now becomes a patch table indexed by position
-			if constexpr (sizeof(C) == 4) {
-				*reinterpret_cast<uint4 *>(&val[lane * 4]) = make_uint4(0, 0, 0, 0);
-			} else {
-				for (int i = lane; i < BLOCK; i += WAVE)
-					val[i] = 0;
-			}
-			wave_sync();
-#pragma unroll
-			for (int it = 0; it < VPL; it++)
-				if (epos[it] < uint32_t(BLOCK))
-					val[epos[it]] = C(hi[it] << nb) & E::MASK;
-			wave_sync();
+		}
+		C u[VPL];
+		if constexpr (sizeof(C) == 4) {
+			const uint4 q = *reinterpret_cast<const uint4 *>(&val[lane * VPL]);
+			u[0] = q.x, u[1] = q.y, u[2] = q.z, u[3] = q.w;
+		} else {
 #pragma unroll
 			for (int s = 0; s < VPL; s++)
-				u[s] |= val[lane * VPL + s];
+				u[s] = val[lane * VPL + s];
 		}
 #pragma unroll
 		for (int s = 0; s < VPL; s++)
@@ -1394,7 +1400,8 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__
 	constexpr int NCH = int((MAXLEN + 1023) / 1024); // 1 KiB pieces: one uint4 per lane each
 	// image: the block's bytes; vals: one slot per value (list scratch, patches)
 	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
-	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK];
+	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK + FIELDS_PAD];
+	__shared__ __attribute__((aligned(16))) C highs[WAVES_PER_WG][BLOCK];
 	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
 	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
@@ -1458,9 +1465,9 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__
 		wave_sync();
 		C v[VPL];
 		if (nv == BLOCK)
-			decode_block<E, true>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
+			decode_block<E, true>(img, len0, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
 		else
-			decode_block<E, false>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
+			decode_block<E, false>(img, len0, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
 		store_block<E>(dst, base, nv, lane, v);
 		wave_sync();
 
@@ -1473,6 +1480,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__
 			im0[c] = im1[c];
 	}
 }
+
+} // namespace oroch_hip
+
+#include "decode_quad.hpp"
+
+namespace oroch_hip {
 
 // ---- host side ----------------------------------------------------------------------
 
@@ -1555,6 +1568,15 @@ static int fused_resident_workgroups()
 // saves, so the two-pass path (select, scan, encode) is the default.
 // OROCH_HIP_SINGLE_PASS=1 selects the single-pass kernel, OROCH_HIP_TWO_PASS=1
 // forces the default explicitly.
+// OROCH_HIP_DECODE_ONE_BLOCK=1 keeps the one-block-per-wavefront decoder for
+// every element type (the 64-bit types always use it); read per call so that
+// tests can compare the two.
+static bool one_block_decode_forced()
+{
+	const char *v = getenv("OROCH_HIP_DECODE_ONE_BLOCK");
+	return v && v[0] == '1';
+}
+
 static bool two_pass_forced()
 {
 	const char *e = getenv("OROCH_HIP_TWO_PASS");
@@ -1762,6 +1784,18 @@ extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *of
 		// evens out blocks of different cost
 		grid = grid < 16384u ? grid : 16384u;
 		profile_scope ps(OROCH_K_DECODE, st);
+		if constexpr (sizeof(typename E::C) == 4) {
+			if (!one_block_decode_forced()) {
+				// four blocks per wavefront
+				const size_t nq = (nb + QUAD - 1) / QUAD;
+				unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
+				qgrid = qgrid < 16384u ? qgrid : 16384u;
+				hipLaunchKernelGGL(k_decode_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
+						   static_cast<const uint8_t *>(src), offsets, n, nb,
+						   static_cast<typename E::S *>(dst));
+				return int(hipGetLastError());
+			}
+		}
 		hipLaunchKernelGGL(k_decode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const uint8_t *>(src), offsets, n, nb,
 				   static_cast<typename E::S *>(dst));

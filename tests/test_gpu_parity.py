@@ -292,3 +292,54 @@ def test_block_statistics_against_oracle(hip, oracle, dt):
         assert int(st[b]["min"]) == mn and int(st[b]["max"]) == mx, (b, st[b], mn, mx)
         assert np.array_equal(st[b]["histogram"][:W + 1].astype(np.uint64), hist[:W + 1]), b
         assert not st[b]["histogram"][W + 1:].any()
+
+
+@pytest.mark.parametrize("dt", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32])
+def test_four_block_decoder_paths(hip, oracle, dt, monkeypatch):
+    """Streams whose blocks share a width, so that the four-blocks-per-wavefront
+    decoder takes its fast path: every width, frame of reference or zigzag,
+    no exceptions / a few (varint lists) / many (bit-packed lists)."""
+    import torch
+
+    dt = np.dtype(dt)
+    W = dt.itemsize * 8
+    rng = np.random.default_rng(4242 + W + (dt.kind == "u"))
+    u = np.dtype("u%d" % dt.itemsize)
+    parts = []
+    for nb in range(1, W + 1):
+        for shape in range(6):
+            nblocks = 8
+            body = rng.integers(0, 1 << nb, size=nblocks * 256, dtype=np.uint64)
+            body[::256] = (1 << nb) - 1          # the width is reached in every block
+            body[1::256] = 0
+            if shape in (2, 3, 4, 5) and nb < W:
+                # exceptions: a few, a dozen, dozens; the last shape clusters them
+                count = {2: 2, 3: 12, 4: 40, 5: 70}[shape]
+                for b in range(nblocks):
+                    pos = rng.choice(np.arange(2, 256), size=min(count, 200), replace=False)
+                    if shape == 5:
+                        pos = np.arange(2, 2 + count)
+                    hi = rng.integers(1, 1 << (W - nb), size=pos.size, dtype=np.uint64)
+                    body[b * 256 + pos] |= hi << np.uint64(nb)
+            origin = 0 if shape == 0 else int(rng.integers(0, 1 << W))
+            v = (body + np.uint64(origin)) & np.uint64((1 << W) - 1)
+            parts.append(v.astype(u).view(dt))
+    a = np.concatenate(parts)
+    exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+    x = dev(a)
+    stream, offs = hip.group_encode(x)
+    assert np.array_equal(host(offs).astype(np.uint64), exp_offs)
+    assert np.array_equal(host(stream), exp)
+    encs = set(int(e) for e in hip.group_select(x)["encoding"])
+    assert {4, 5, 6} & encs == {4, 5, 6} or W == 8, encs
+    back = hip.group_decode(stream, offs, a.size, dt)
+    assert np.array_equal(host(back).view(dt), a)
+    # the one-block-per-wavefront decoder agrees
+    monkeypatch.setenv("OROCH_HIP_DECODE_ONE_BLOCK", "1")
+    back1 = hip.group_decode(stream, offs, a.size, dt)
+    monkeypatch.delenv("OROCH_HIP_DECODE_ONE_BLOCK")
+    assert torch.equal(back1, back)
+    # a stream that does not end on a four-block boundary, with a short last block
+    for cut in (256 * 5 + 17, 256 * 2, 255, 1):
+        s2, o2 = hip.group_encode(x[:cut])
+        assert np.array_equal(host(hip.group_decode(s2, o2, cut, dt)).view(dt), a[:cut])
