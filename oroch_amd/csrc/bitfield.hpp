@@ -109,32 +109,43 @@ __device__ __forceinline__ void deposit(C u, uint32_t (&w)[4])
 	}
 }
 
-template <typename C, int NB, int K0>
+// MASKED: the values may have bits above NB (bitpfr packs the low bits of
+// every value, bitpck.h:94); they are cut here.
+template <typename C, int NB, bool MASKED>
+__device__ __forceinline__ C low_bits(C u)
+{
+	if constexpr (MASKED && NB < int(sizeof(C)) * 8)
+		return u & C((C(1) << NB) - 1);
+	else
+		return u;
+}
+
+template <typename C, int NB, bool MASKED, int K0>
 __device__ __forceinline__ void pack_from(const C *in, uint32_t (&w)[4])
 {
 	constexpr int CAP = 128 / NB;
 	if constexpr (K0 < CAP) {
-		deposit<C, NB, K0>(in[K0], w);
+		deposit<C, NB, K0>(low_bits<C, NB, MASKED>(in[K0]), w);
 		if constexpr (K0 + 1 < CAP)
-			deposit<C, NB, K0 + 1>(in[K0 + 1], w);
+			deposit<C, NB, K0 + 1>(low_bits<C, NB, MASKED>(in[K0 + 1]), w);
 		if constexpr (K0 + 2 < CAP)
-			deposit<C, NB, K0 + 2>(in[K0 + 2], w);
+			deposit<C, NB, K0 + 2>(low_bits<C, NB, MASKED>(in[K0 + 2]), w);
 		if constexpr (K0 + 3 < CAP)
-			deposit<C, NB, K0 + 3>(in[K0 + 3], w);
+			deposit<C, NB, K0 + 3>(low_bits<C, NB, MASKED>(in[K0 + 3]), w);
 		if constexpr (K0 + 4 < CAP) {
 			asm volatile("" ::: "memory");
-			pack_from<C, NB, K0 + 4>(in, w);
+			pack_from<C, NB, MASKED, K0 + 4>(in, w);
 		}
 	}
 }
 
-// Packed block j from slots[j * capacity ..), each value below 2^NB.
-template <typename C, int NB>
+// Packed block j from slots[j * capacity ..).
+template <typename C, int NB, bool MASKED = false>
 __device__ __forceinline__ void pack_fields(const C *slots, int j, uint32_t (&w)[4])
 {
 	w[0] = w[1] = w[2] = w[3] = 0;
 	asm volatile("" : "+v"(j));
-	pack_from<C, NB, 0>(slots + j * (128 / NB), w);
+	pack_from<C, NB, MASKED, 0>(slots + j * (128 / NB), w);
 }
 
 // Widths below this keep the lane-per-value code: a block of such narrow

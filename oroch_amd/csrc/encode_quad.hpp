@@ -1,0 +1,333 @@
+// encode_quad.hpp -- the encoder's fast path: four consecutive blocks per
+// wavefront, sixteen lanes per block (the counterpart of decode_quad.hpp).
+//
+// Works from the descriptors the selection pass left behind.  Lane (g, sub)
+// holds values 16 sub .. 16 sub + 15 of block g; the deltas go through an LDS
+// slot array, from which lane p of the wavefront packs 16-byte word p of the
+// quad with compile-time field positions and stores it straight to the stream.
+// The header is produced one byte per lane, exception lists are written by
+// the lanes that own exceptions.  Covers bitpck, bitfor and bitpfr blocks of
+// one common width; anything else goes block by block through encode_block.
+//
+// Included by group.hip after encode_block and decode_quad.hpp; 8-, 16- and
+// 32-bit element types.
+#pragma once
+
+namespace oroch_hip {
+
+constexpr int VPQ = BLOCK / GROUP;   // values per lane and block
+constexpr int TAIL_BYTES = 256;      // exception lists + padding a group stages in LDS
+
+// Inclusive prefix maximum within each row of 16 lanes; values are >= -1.
+__device__ __forceinline__ int row_scan_max(int x)
+{
+	int y;
+	y = dpp_mov<0x111>(-1, x); x = x > y ? x : y;
+	y = dpp_mov<0x112>(-1, x); x = x > y ? x : y;
+	y = dpp_mov<0x114>(-1, x); x = x > y ? x : y;
+	y = dpp_mov<0x118>(-1, x); x = x > y ? x : y;
+	return x;
+}
+
+// Sixteen consecutive elements at p (16-byte aligned) as raw W-bit patterns.
+template <typename E>
+__device__ __forceinline__ void load16(const typename E::S *p, typename E::C (&v)[VPQ])
+{
+	const uint4 *q = reinterpret_cast<const uint4 *>(p);
+	if constexpr (E::BYTES == 4) {
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint4 a = q[k];
+			v[4 * k] = a.x, v[4 * k + 1] = a.y, v[4 * k + 2] = a.z, v[4 * k + 3] = a.w;
+		}
+	} else if constexpr (E::BYTES == 2) {
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const uint4 a = q[k];
+			const uint32_t d[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				v[8 * k + 2 * i] = d[i] & 0xffffu;
+				v[8 * k + 2 * i + 1] = d[i] >> 16;
+			}
+		}
+	} else {
+		const uint4 a = q[0];
+		const uint32_t d[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			v[4 * i] = d[i] & 0xffu;
+			v[4 * i + 1] = (d[i] >> 8) & 0xffu;
+			v[4 * i + 2] = (d[i] >> 16) & 0xffu;
+			v[4 * i + 3] = d[i] >> 24;
+		}
+	}
+}
+
+// Lane p, p + 64, ... packs word p of the quad (word j of block gp) from the
+// slots and stores it at its place in the stream.
+template <typename E, int NB>
+__device__ __forceinline__ void pack_quad_words(const typename E::C *slots, uint32_t data_at, int lane,
+						uint8_t *out)
+{
+	using C = typename E::C;
+	constexpr uint32_t NBLK = (BLOCK + 128 / NB - 1) / (128 / NB);
+	constexpr uint32_t P = QUAD * NBLK;
+#pragma unroll
+	for (uint32_t r = 0; r < (P + WAVE - 1) / WAVE; r++) {
+		const uint32_t p = uint32_t(lane) + r * WAVE;
+		const uint32_t gp = (p >= NBLK ? 1u : 0u) + (p >= 2 * NBLK ? 1u : 0u) + (p >= 3 * NBLK ? 1u : 0u);
+		const uint32_t j = p - gp * NBLK;
+		const uint32_t at = lane_gather(data_at, int(gp * GROUP));
+		if (p < P) {
+			uint32_t w[4];
+			pack_fields<C, NB, true>(slots + gp * SLOT_STRIDE, int(j), w);
+			*reinterpret_cast<uint4 *>(out + at + j * 16u) = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+	}
+}
+
+template <typename E, int LO, int HI>
+__device__ __forceinline__ void pack_quad_dispatch(uint32_t nb, const typename E::C *slots,
+						   uint32_t data_at, int lane, uint8_t *out)
+{
+	if constexpr (LO == HI) {
+		pack_quad_words<E, LO>(slots, data_at, lane, out);
+	} else {
+		constexpr int MID = (LO + HI) / 2;
+		if (nb <= uint32_t(MID))
+			pack_quad_dispatch<E, LO, MID>(nb, slots, data_at, lane, out);
+		else
+			pack_quad_dispatch<E, MID + 1, HI>(nb, slots, data_at, lane, out);
+	}
+}
+
+// da, db: the two halves of this lane's block descriptor (put_desc layout);
+// off: the block's stream offset.  Returns false, with nothing written, if the
+// quad does not qualify.
+template <typename E>
+__device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], const uint4 da,
+						  const uint4 db, uint64_t off, int lane,
+						  typename E::C *slots, uint8_t *tails, uint8_t *heads,
+						  const uint4 *wt, uint8_t *dst)
+{
+	using C = typename E::C;
+	static_assert(sizeof(C) == 4, "element types up to 32 bits");
+	asm volatile("" : "+v"(lane)); // see decode_quad_fast
+	const int g = lane / GROUP, sub = lane % GROUP;
+
+	const C origin = da.x;
+	const uint32_t dataspace = da.z, size = da.w;
+	const uint32_t metaspace = db.x & 0xffffu, nout = db.x >> 16;
+	const uint32_t enc = (db.y >> 16) & 0xffu, nb = db.y >> 24;
+	const uint32_t ienc = db.z & 0xffu, inb = (db.z >> 8) & 0xffu;
+	const uint32_t venc = (db.z >> 16) & 0xffu, vnb = db.z >> 24;
+	const uint32_t doff = (metaspace + 7u) & ~7u; // integer_group.h:50-52
+	const bool width_ok = nb >= uint32_t(FIELDS_MIN_NB) && nb <= uint32_t(E::W);
+	const uint32_t pck = wt[width_ok ? nb : 1u].w;
+	const uint32_t list_at = doff + pck;
+	bool ok = (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) && width_ok &&
+		  dataspace >= pck && size >= list_at && size - list_at <= uint32_t(TAIL_BYTES);
+	const uint32_t nb_u = uniform(nb);
+	ok = ok && nb == nb_u;
+	const uint64_t all = __ballot(ok);
+	if ((uint32_t(all) & uint32_t(all >> 32)) != 0xffffffffu)
+		return false;
+
+	// stream positions relative to the quad's first block
+	const uint64_t start = uniform(off);
+	const uint32_t rel = uint32_t(off - start);
+	uint8_t *out = dst + start;
+
+	// deltas (or zigzag images) of all values into the slots, in full: the
+	// packer cuts them to the width, the exception lists need the rest
+	C *mine = slots + g * SLOT_STRIDE;
+	const bool has_exc = enc == OROCH_BITPFR;
+	const bool zig = E::sgn && enc == OROCH_BITPCK;
+	const C org = enc == OROCH_BITPCK ? C(0) : origin;
+	C u[VPQ];
+	if (E::sgn && __ballot(zig) != 0) {
+#pragma unroll
+		for (int i = 0; i < VPQ; i++)
+			u[i] = zig ? zz<E>(v[i]) : C((v[i] - org) & E::MASK);
+	} else {
+#pragma unroll
+		for (int i = 0; i < VPQ; i++)
+			u[i] = C((v[i] - org) & E::MASK);
+	}
+#pragma unroll
+	for (int k = 0; k < VPQ / 4; k++)
+		*reinterpret_cast<uint4 *>(&mine[sub * VPQ + 4 * k]) = make_uint4(u[4 * k], u[4 * k + 1], u[4 * k + 2], u[4 * k + 3]);
+	// the last packed word of a block reads past value 255: zeros there
+	*reinterpret_cast<uint2 *>(&mine[BLOCK + 2 * sub]) = make_uint2(0, 0);
+	// exception list staging starts out as zeros (it also supplies the padding)
+	uint8_t *tail = tails + g * TAIL_BYTES;
+	*reinterpret_cast<uint4 *>(tail + 16 * sub) = make_uint4(0, 0, 0, 0);
+	// which of my values are exceptions
+	uint32_t m = 0;
+	if (__ballot(has_exc) != 0) {
+#pragma unroll
+		for (int i = 0; i < VPQ; i++) {
+			const uint32_t hi = nb_u >= 32u ? 0u : uint32_t(u[i] >> nb_u);
+			m |= (hi ? 1u : 0u) << i;
+		}
+		m = has_exc ? m : 0u;
+	}
+	wave_sync();
+
+	pack_quad_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, slots, rel + doff, lane, out);
+
+	// metadata, integer_codec.h:128-151, 177-182, 196-204: lane `sub` makes
+	// byte `sub` of the (at most 11-byte) header
+	{
+		const bool has_o = enc != OROCH_BITPCK;
+		const C zo = zz<E>(origin);
+		uint32_t olen = (bitlen(zo) + 6u) / 7u;
+		olen = has_o ? (olen ? olen : 1u) : 0u;
+		const uint32_t pos = uint32_t(sub);
+		const uint32_t p_nb = 1u + olen, p_nout = p_nb + 1u;
+		const uint32_t nlen = nout >= 128u ? 2u : 1u;
+		const uint32_t p_i = p_nout + nlen, p_v = p_i + 1u;
+		uint32_t byte = 0;
+		if (pos == 0) {
+			byte = enc;
+		} else if (pos <= olen) {
+			const uint32_t k = pos - 1u;
+			byte = (uint32_t(zo >> (7u * k)) & 0x7fu) | (k + 1u < olen ? 0x80u : 0u);
+		} else if (pos == p_nb) {
+			byte = nb;
+		} else if (has_exc) {
+			if (pos == p_nout)
+				byte = (nout & 0x7fu) | (nlen == 2u ? 0x80u : 0u);
+			else if (nlen == 2u && pos == p_nout + 1u)
+				byte = nout >> 7;
+			else if (pos == p_i)
+				byte = ienc == OROCH_BITPCK ? inb : 0u;
+			else if (pos == p_v)
+				byte = venc == OROCH_BITPCK ? vnb : 0u;
+		}
+		uint8_t *head = heads + g * 16;
+		head[sub] = uint8_t(byte);
+		wave_sync();
+		if (uint32_t(sub) * 8u < doff)
+			*reinterpret_cast<uint2 *>(out + rel + sub * 8) = *reinterpret_cast<const uint2 *>(head + sub * 8);
+	}
+
+	// exception lists, integer_codec.h:563-581: gap-coded positions
+	// (offset.h:55-60) then high parts, bit-packed or as varints
+	if (__ballot(has_exc) != 0) {
+		const uint32_t cnt = uint32_t(__popc(m));
+		const uint32_t before = row_scan_sum(cnt) - cnt;
+		const int last = m ? sub * VPQ + 31 - int(__clz(m)) : -1;
+		const int upto = row_scan_max(last);
+		const int prev0 = dpp_mov<0x111>(-1, upto); // last exception in lower lanes
+		const uint4 iw = wt[inb ? inb : 1u], vw = wt[vnb ? vnb : 1u];
+		// first pass over my exceptions: how many list bytes they take
+		uint32_t ib = 0, vb = 0;
+		{
+			uint32_t mm = m;
+			int prev = prev0;
+			while (__ballot(mm != 0) != 0) {
+				if (mm) {
+					const int pos = sub * VPQ + int(__builtin_ctz(mm));
+					const uint32_t gap = uint32_t(pos - prev - 1);
+					prev = pos;
+					const C hi = mine[pos] >> nb_u;
+					ib += gap >= 128u ? 2u : 1u;
+					vb += vsp(hi);
+					mm &= mm - 1u;
+				}
+			}
+		}
+		const uint32_t isum = row_scan_sum(ib), vsum = row_scan_sum(vb);
+		const uint32_t ilen = ienc == OROCH_BITPCK ? 16u * __umulhi(nout + iw.x - 1u, iw.y)
+							    : lane_gather(isum, g * GROUP + GROUP - 1);
+		uint32_t io = isum - ib, vo = ilen + vsum - vb, r = before;
+		uint32_t *tail32 = reinterpret_cast<uint32_t *>(tail);
+		{
+			uint32_t mm = m;
+			int prev = prev0;
+			while (__ballot(mm != 0) != 0) {
+				if (mm) {
+					const int pos = sub * VPQ + int(__builtin_ctz(mm));
+					const uint32_t gap = uint32_t(pos - prev - 1);
+					prev = pos;
+					const C hi = mine[pos] >> nb_u;
+					if (ienc == OROCH_BITPCK) {
+						const uint32_t bk = __umulhi(r, iw.y);
+						lds_or_bits(tail32, bk * 128u + (r - bk * iw.x) * inb, gap);
+					} else {
+						tail[io++] = uint8_t((gap & 0x7fu) | (gap >= 128u ? 0x80u : 0u));
+						if (gap >= 128u)
+							tail[io++] = uint8_t(gap >> 7);
+					}
+					if (venc == OROCH_BITPCK) {
+						const uint32_t bk = __umulhi(r, vw.y);
+						lds_or_bits(tail32, ilen * 8u + bk * 128u + (r - bk * vw.x) * vnb, hi);
+					} else {
+						vo = put_varint(tail, vo, uint64_t(hi));
+					}
+					r++;
+					mm &= mm - 1u;
+				}
+			}
+		}
+	}
+	wave_sync();
+	// lists and the zero padding up to the block's 16-byte boundary
+	for (uint32_t k = uint32_t(sub) * 8u; k < size - list_at; k += GROUP * 8u)
+		*reinterpret_cast<uint2 *>(out + rel + list_at + k) = *reinterpret_cast<const uint2 *>(tail + k);
+	return true;
+}
+
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode_quad(const typename E::S *__restrict__ src,
+								      size_t n, size_t nblocks,
+								      const oroch_block_desc *__restrict__ desc,
+								      const uint64_t *__restrict__ offsets,
+								      uint8_t *__restrict__ dst)
+{
+	using C = typename E::C;
+	__shared__ __attribute__((aligned(16))) C slotss[WAVES_PER_WG][QUAD * SLOT_STRIDE];
+	__shared__ __attribute__((aligned(16))) uint8_t tailss[WAVES_PER_WG][QUAD * TAIL_BYTES];
+	__shared__ __attribute__((aligned(16))) uint8_t headss[WAVES_PER_WG][QUAD * 16];
+	__shared__ __attribute__((aligned(16))) uint32_t images[WAVES_PER_WG][image_bytes<E>() / 4];
+	__shared__ uint4 wt[65];
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	load_width_table(wt);
+	const size_t nquads = (nblocks + QUAD - 1) / QUAD;
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
+	for (size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave; q < nquads; q += stride) {
+		const size_t blk0 = q * QUAD;
+		bool done = false;
+		if (blk0 + QUAD <= nblocks && (blk0 + QUAD) * BLOCK <= n) {
+			const size_t blk = blk0 + size_t(lane / GROUP);
+			C v[VPQ];
+			load16<E>(src + blk * BLOCK + size_t(lane % GROUP) * VPQ, v);
+			const uint4 *dq = reinterpret_cast<const uint4 *>(desc + blk);
+			const uint4 da = dq[0], db = dq[1];
+			const uint64_t off = offsets[blk];
+			done = encode_quad_fast<E>(v, da, db, off, lane, slotss[wave], tailss[wave], headss[wave],
+						   wt, dst);
+		}
+		if (!done) {
+			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
+				const size_t blk = blk0 + size_t(b);
+				const int nv = block_count(n, blk);
+				C v[VPL];
+				load_block<E>(src, blk * BLOCK, nv, lane, v);
+				selection<C> sel;
+				get_desc(&desc[blk], sel);
+				const uint64_t off = uniform(offsets[blk]);
+				const uint32_t len = nv == BLOCK
+							     ? encode_block<E, true>(v, nv, lane, sel, wt, images[wave])
+							     : encode_block<E, false>(v, nv, lane, sel, wt, images[wave]);
+				flush_image(images[wave], len, dst + off, lane);
+				wave_sync();
+			}
+		}
+		wave_sync();
+	}
+}
+
+} // namespace oroch_hip

@@ -1484,6 +1484,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__
 } // namespace oroch_hip
 
 #include "decode_quad.hpp"
+#include "encode_quad.hpp"
 
 namespace oroch_hip {
 
@@ -1574,6 +1575,12 @@ static int fused_resident_workgroups()
 static bool one_block_decode_forced()
 {
 	const char *v = getenv("OROCH_HIP_DECODE_ONE_BLOCK");
+	return v && v[0] == '1';
+}
+
+static bool one_block_encode_forced()
+{
+	const char *v = getenv("OROCH_HIP_ENCODE_ONE_BLOCK");
 	return v && v[0] == '1';
 }
 
@@ -1698,6 +1705,17 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 			if (r)
 				return r;
 			profile_scope ps(OROCH_K_ENCODE, st);
+			if constexpr (sizeof(typename E::C) == 4) {
+				if (!one_block_encode_forced()) {
+					const size_t nq = (nb + QUAD - 1) / QUAD;
+					unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
+					qgrid = qgrid < 16384u ? qgrid : 16384u;
+					hipLaunchKernelGGL(k_encode_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
+							   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
+							   static_cast<uint8_t *>(dst));
+					return int(hipGetLastError());
+				}
+			}
 			hipLaunchKernelGGL(k_encode<E>, dim3(grid < 16384u ? grid : 16384u),
 					   dim3(WAVE * WAVES_PER_WG), 0, st,
 					   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
