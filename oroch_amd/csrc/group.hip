@@ -1485,6 +1485,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__
 
 #include "decode_quad.hpp"
 #include "encode_quad.hpp"
+#include "select_quad.hpp"
 
 namespace oroch_hip {
 
@@ -1597,6 +1598,30 @@ static bool two_pass_forced()
 
 using namespace oroch_hip;
 
+// Launches the selection pass: four blocks per wavefront for element types up
+// to 32 bits (unless OROCH_HIP_SELECT_ONE_BLOCK=1), one block per wavefront
+// otherwise.
+template <typename E>
+static int launch_select(const void *src, size_t n, size_t nb, oroch_block_desc *desc, uint32_t *sizes,
+			 hipStream_t st)
+{
+	if constexpr (sizeof(typename E::C) == 4) {
+		const char *v = getenv("OROCH_HIP_SELECT_ONE_BLOCK");
+		if (!(v && v[0] == '1')) {
+			const size_t nq = (nb + QUAD - 1) / QUAD;
+			unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
+			qgrid = qgrid < 16384u ? qgrid : 16384u;
+			hipLaunchKernelGGL(k_select_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
+					   static_cast<const typename E::S *>(src), n, nb, desc, sizes);
+			return int(hipGetLastError());
+		}
+	}
+	const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
+	hipLaunchKernelGGL(k_select<E>, dim3(grid < 16384u ? grid : 16384u), dim3(WAVE * WAVES_PER_WG), 0, st,
+			   static_cast<const typename E::S *>(src), n, nb, desc, sizes);
+	return int(hipGetLastError());
+}
+
 extern "C" size_t oroch_group_bound(int dtype, size_t n)
 {
 	if (dtype < 0 || dtype > 7)
@@ -1627,13 +1652,8 @@ extern "C" int oroch_group_select(int dtype, const void *src, size_t n, oroch_bl
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
-		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
 		profile_scope ps(OROCH_K_SELECT, st);
-		const unsigned sgrid = grid < 16384u ? grid : 16384u;
-		hipLaunchKernelGGL(k_select<E>, dim3(sgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
-				   static_cast<const typename E::S *>(src), n, nb, desc,
-				   static_cast<uint32_t *>(nullptr));
-		return int(hipGetLastError());
+		return launch_select<E>(src, n, nb, desc, nullptr, st);
 	});
 }
 
@@ -1691,10 +1711,7 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 			int r;
 			{
 				profile_scope ps(OROCH_K_SELECT, st);
-				const unsigned sgrid = grid < 16384u ? grid : 16384u;
-				hipLaunchKernelGGL(k_select<E>, dim3(sgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
-						   static_cast<const typename E::S *>(src), n, nb, w.desc, w.sizes);
-				r = int(hipGetLastError());
+				r = launch_select<E>(src, n, nb, w.desc, w.sizes, st);
 			}
 			if (r)
 				return r;

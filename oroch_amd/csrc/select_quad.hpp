@@ -1,0 +1,375 @@
+// select_quad.hpp -- codec selection for four consecutive full blocks per
+// wavefront, sixteen lanes per block (integer_codec.h:234-384 with
+// integer_stats.h:48-53, 74-80).  Same rule and same candidate order as
+// select_full; what changes is where the work sits: everything that is uniform
+// per block lives in the vector registers of the block's 16-lane group, so the
+// four blocks advance together and nothing is left for the scalar unit but the
+// loop control.  Reductions and scans are DPP row operations (a row is a
+// group).  Each lane looks after two candidate widths, sub + 1 and sub + 17.
+//
+// Included by group.hip after select_full and encode_quad.hpp; 8-, 16- and
+// 32-bit element types.
+#pragma once
+
+namespace oroch_hip {
+
+constexpr int HQ_DWORDS = 196;  // per group: 33 bins x 4 copies; 196 puts the groups' tables 4 banks apart
+constexpr int NO_DWORDS = 64;   // per group: exception counts by width, zero above the widest
+constexpr int PW_ENTRIES = 34;  // per group: per-width candidate parameters
+
+template <typename V, typename Op>
+__device__ __forceinline__ V row_allreduce(V x, V ident, Op op)
+{
+	x = op(x, dpp_mov<0xb1>(ident, x));
+	x = op(x, dpp_mov<0x4e>(ident, x));
+	x = op(x, dpp_mov<0x124>(ident, x));
+	x = op(x, dpp_mov<0x128>(ident, x));
+	return x;
+}
+__device__ __forceinline__ uint32_t row_sum(uint32_t x)
+{
+	return row_allreduce(x, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+}
+__device__ __forceinline__ uint32_t row_max(uint32_t x)
+{
+	return row_allreduce(x, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+}
+__device__ __forceinline__ uint32_t row_min(uint32_t x)
+{
+	return row_allreduce(x, ~0u, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
+}
+
+// v_ffbh_u32: leading zeros of x, -1 for x == 0 (the builtin's result is
+// undefined there, the instruction's is not).
+__device__ __forceinline__ int leading_zeros(uint32_t x)
+{
+	int r;
+	asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+	return r;
+}
+
+// The 16 bits of a ballot that belong to this lane's group.
+__device__ __forceinline__ uint32_t group_bits(uint64_t ballot, int g)
+{
+	const uint32_t half = (g & 2) ? uint32_t(ballot >> 32) : uint32_t(ballot);
+	return (half >> ((g & 1) * 16)) & 0xffffu;
+}
+
+// Group-uniform outcome of selection, one copy per lane.
+struct quad_selection
+{
+	uint32_t encoding, nbits, metaspace, dataspace, noutliers, ienc, inbits, venc, vnbits, origin;
+};
+
+// hq: QUAD * HQ_DWORDS, no: QUAD * NO_DWORDS, pw: QUAD * PW_ENTRIES uint4 of LDS
+// owned by this wavefront.
+template <typename E>
+__device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int lane, uint32_t *hq,
+					    uint32_t *no, uint4 *pw, const uint4 *wt, quad_selection &sel)
+{
+	using C = typename E::C;
+	static_assert(sizeof(C) == 4, "element types up to 32 bits");
+	asm volatile("" : "+v"(lane)); // see decode_quad_fast
+	const int g = lane / GROUP, sub = lane % GROUP;
+	const uint32_t bA = uint32_t(sub) + 1u, bB = uint32_t(sub) + 17u;
+
+	sel.encoding = OROCH_NORMAL;
+	sel.nbits = 0;
+	sel.metaspace = 1;
+	sel.dataspace = 0;
+	sel.noutliers = 0;
+	sel.ienc = sel.venc = OROCH_NORMAL;
+	sel.inbits = sel.vnbits = 0;
+	sel.origin = 0;
+
+	// integer_stats.h:88-95: the minimum (signed compare for int32, else on
+	// order-preserving unsigned keys)
+	C mn;
+	if constexpr (E::sgn && E::W == 32) {
+		int32_t smin = int32_t(v[0]);
+#pragma unroll
+		for (int i = 1; i < VPQ; i++)
+			smin = int32_t(v[i]) < smin ? int32_t(v[i]) : smin;
+		mn = C(row_min(uint32_t(smin) ^ 0x80000000u) ^ 0x80000000u);
+	} else {
+		C kmin = v[0] ^ E::FLIP;
+#pragma unroll
+		for (int i = 1; i < VPQ; i++) {
+			const C k = v[i] ^ E::FLIP;
+			kmin = k < kmin ? k : kmin;
+		}
+		mn = row_min(kmin) ^ E::FLIP;
+	}
+	const uint32_t vo = vsp(zz<E>(mn));
+
+	// Bit-length histograms of v - min and of zigzag(v), integer_stats.h:97-102.
+	// Bins are indexed by leading zeros + 1 (v_ffbh_u32 gives -1 for zero, so
+	// bin 0 is "value zero" and bin c + 1 is bit length 32 - c) and are four
+	// dwords each (one per sub & 3, to spread same-address atomics): delta
+	// count in the low half, zigzag count in the high half.
+	uint32_t *table = hq + g * HQ_DWORDS;
+#pragma unroll
+	for (int k = 0; k < HQ_DWORDS / (GROUP * 4); k++)
+		*reinterpret_cast<uint4 *>(&table[(k * GROUP + sub) * 4]) = make_uint4(0, 0, 0, 0);
+	uint32_t *nog = no + g * NO_DWORDS;
+	nog[32 + sub] = 0;
+	nog[48 + sub] = 0;
+	wave_sync();
+	uint32_t *mine = table + 4 + (sub & 3);
+	// leading-zero counts of the deltas, four to a register (value 4j + r in
+	// byte j of lz[r]; 127 for a zero delta)
+	uint32_t lz[4] = {0, 0, 0, 0};
+#pragma unroll
+	for (int i = 0; i < VPQ; i++) {
+		const int cd = leading_zeros(uint32_t((v[i] - mn) & E::MASK));
+		const int cz = leading_zeros(uint32_t(zz<E>(v[i])));
+		atomicAdd(&mine[cd * 4], 1u);
+		atomicAdd(&mine[cz * 4], 0x10000u);
+		lz[i & 3] |= (uint32_t(cd) & 0x7fu) << (8 * (i >> 2));
+	}
+	wave_sync();
+	// width b <-> bin 33 - b
+	const uint4 qa = *reinterpret_cast<const uint4 *>(&table[(33u - bA) * 4]);
+	const uint4 qb = *reinterpret_cast<const uint4 *>(&table[(33u - bB) * 4]);
+	const uint4 q0 = *reinterpret_cast<const uint4 *>(&table[0]);
+	const uint32_t sa = qa.x + qa.y + qa.z + qa.w;
+	const uint32_t sb = qb.x + qb.y + qb.z + qb.w;
+	const uint32_t s0 = q0.x + q0.y + q0.z + q0.w;
+	const uint32_t dA = sa & 0xffffu, zA = sa >> 16, dB = sb & 0xffffu, zB = sb >> 16;
+	const uint32_t zero_d = s0 & 0xffffu, zero_z = s0 >> 16;
+	const bool constant = zero_d == uint32_t(BLOCK); // integer_codec.h:255-264, applied at the end
+
+	// the two varint footprints, integer_codec.h:483-489, from the histograms
+	const uint32_t wA = vsp_bits(bA), wB = vsp_bits(bB);
+	const uint32_t t = row_sum(dA * wA + dB * wB + ((zA * wA + zB * wB) << 16));
+	const uint32_t vfs = (t & 0xffffu) + zero_d, vis = (t >> 16) + zero_z;
+	// widest delta and widest zigzag image
+	const uint32_t nbmax = row_max(dB ? bB : (dA ? bA : 0u));
+	uint32_t nbz = row_max(zB ? bB : (zA ? bA : 0u));
+	nbz = nbz ? nbz : 1u;
+
+	// select_basic, integer_codec.h:422-496; strictly smaller replaces (:413)
+	uint32_t best = BLOCK * E::BYTES, bmeta0 = 0;
+	{
+		const uint32_t total = wt[nbz].w + 1u;
+		if (total < best) {
+			best = total;
+			bmeta0 = 1;
+			sel.encoding = OROCH_BITPCK;
+			sel.nbits = nbz;
+		}
+	}
+	{
+		const uint32_t total = wt[nbmax ? nbmax : 1u].w + 1u + vo;
+		if (total < best) {
+			best = total;
+			bmeta0 = 1 + vo;
+			sel.encoding = OROCH_BITFOR;
+			sel.nbits = nbmax;
+			sel.origin = mn;
+		}
+		if (vis < best) {
+			best = vis;
+			bmeta0 = 0;
+			sel.encoding = OROCH_VARINT;
+			sel.nbits = 0;
+			sel.origin = 0;
+		}
+		if (vfs + vo < best) {
+			best = vfs + vo;
+			bmeta0 = vo;
+			sel.encoding = OROCH_VARFOR;
+			sel.nbits = 0;
+			sel.origin = mn;
+		}
+	}
+	sel.metaspace = 1 + bmeta0;
+	sel.dataspace = best - bmeta0;
+
+	// ---- patched frame of reference, integer_codec.h:280-383 ----
+	// values longer than b bits, for this lane's two widths
+	const uint32_t pA = row_scan_sum(dA), pB = row_scan_sum(dB);
+	const uint32_t totB = lane_gather(pB, g * GROUP + GROUP - 1);
+	const uint32_t noutA = uint32_t(BLOCK) - zero_d - pA, noutB = totB - pB;
+	nog[bA - 1] = noutA; // entry b - 1 holds the count for width b
+	nog[bB - 1] = noutB;
+	wave_sync();
+	// varint bytes of the high parts: each value of bit length k > b costs
+	// ceil((k - b) / 7), i.e. the sum over j >= 0 of nout(b + 7j) (:308-312)
+	const uint32_t valvarA = noutA + nog[bA + 6] + nog[bA + 13] + nog[bA + 20] + nog[bA + 27];
+	const uint32_t valvarB = noutB + nog[(bB + 6) & 63] + nog[(bB + 13) & 63] + nog[(bB + 20) & 63] +
+				 nog[(bB + 27) & 63];
+	const uint32_t basic_meta = 1 + vo;
+	uint4 *pwg = pw + g * PW_ENTRIES;
+	bool candA, candB;
+	{
+		const bool active = bA < nbmax && dA != 0;
+		const uint32_t xmeta = 2 + (noutA < 128u ? 1u : 2u);
+		const uint4 cm = wt[active ? nbmax - bA : 1u];
+		const uint32_t valpck = 16u * __umulhi(noutA + cm.x - 1u, cm.y);
+		const uint32_t venc = valpck < valvarA ? OROCH_BITPCK : OROCH_VARINT;
+		const uint32_t vdata = valpck < valvarA ? valpck : valvarA;
+		const uint32_t indmin = noutA > 128u ? 32u : 16u; // min(pck(nout, 1), 256), nout in 1..255
+		const uint32_t fixed = basic_meta + xmeta + wt[bA].w + vdata;
+		const uint32_t est = fixed + indmin;
+		candA = active && est < best;
+		pwg[bA] = make_uint4(est, fixed, noutA | (venc << 16) | (xmeta << 24), 0);
+	}
+	{
+		const bool active = bB < nbmax && dB != 0;
+		const uint32_t xmeta = 2 + (noutB < 128u ? 1u : 2u);
+		const uint4 cm = wt[active ? nbmax - bB : 1u];
+		const uint32_t valpck = 16u * __umulhi(noutB + cm.x - 1u, cm.y);
+		const uint32_t venc = valpck < valvarB ? OROCH_BITPCK : OROCH_VARINT;
+		const uint32_t vdata = valpck < valvarB ? valpck : valvarB;
+		const uint32_t indmin = noutB > 128u ? 32u : 16u;
+		const uint32_t fixed = basic_meta + xmeta + wt[bB <= 32u ? bB : 32u].w + vdata;
+		const uint32_t est = fixed + indmin;
+		candB = bB <= 32u && active && est < best;
+		pwg[bB <= 32u ? bB : 33u] = make_uint4(est, fixed, noutB | (venc << 16) | (xmeta << 24), 0);
+	}
+	candA = candA && !constant;
+	candB = candB && !constant;
+	wave_sync();
+
+	// Replay of the reference's ascending loop, all four blocks in step: each
+	// group takes its narrowest remaining candidate.  `best` only shrinks, so
+	// a width that failed the gate (:327-335) against the initial value fails later.
+	uint32_t cands = group_bits(__ballot(candA), g) | (group_bits(__ballot(candB), g) << 16); // bit b - 1
+	while (__ballot(cands != 0) != 0) {
+		const bool live = cands != 0;
+		const uint32_t bL = uint32_t(__builtin_ctz(cands | 0x80000000u)) + 1u;
+		cands &= cands - 1u;
+		const uint4 par = pwg[live ? bL : 1u];
+		const uint32_t estL = par.x, fixedL = par.y, noutL = par.z & 0xffffu;
+		const bool tryit = live && estL < best;
+		if (__ballot(tryit) == 0)
+			continue;
+		// My exceptions at this width, bit i for value i: bit length above bL,
+		// i.e. fewer than 32 - bL leading zeros (a zero delta reads as 127).
+		const uint32_t thr = (32u - bL) * 0x01010101u;
+		// bit 7 of a byte comes out set iff that byte of lz is >= 32 - bL: not
+		// an exception.  Flags land at bit 8j + r for value 4j + r, then move
+		// together into 16 bits.
+		const uint32_t c = ((((lz[0] | 0x80808080u) - thr) & 0x80808080u) >> 7) |
+				   ((((lz[1] | 0x80808080u) - thr) & 0x80808080u) >> 6) |
+				   ((((lz[2] | 0x80808080u) - thr) & 0x80808080u) >> 5) |
+				   ((((lz[3] | 0x80808080u) - thr) & 0x80808080u) >> 4);
+		const uint32_t ne = (c & 0xfu) | ((c >> 4) & 0xf0u) | ((c >> 8) & 0xf00u) | ((c >> 12) & 0xf000u);
+		const uint32_t m = ~ne & 0xffffu; // my exceptions, bit i for value i
+		// Index gaps, :338-351.  The gap in front of my first exception reaches
+		// back to the last exception of the lanes before me; the gaps between
+		// my own exceptions are runs of zeros inside m.
+		const uint32_t hb = 31u - uint32_t(__clz(m | 1u));
+		const int lastpos = m ? sub * VPQ + int(hb) : -1;
+		const int prev0 = dpp_mov<0x111>(-1, row_scan_max(lastpos));
+		const uint32_t fb = uint32_t(__builtin_ctz(m | 0x10000u));
+		const uint32_t gfirst = m ? uint32_t(sub * VPQ + int(fb) - prev0 - 1) : 0u;
+		// zeros strictly between my lowest and highest exception
+		const uint32_t z1 = ~m & ((2u << hb) - 1u) & ~((1u << fb) - 1u) & 0xffffu;
+		const uint32_t z2 = z1 & (z1 >> 1), z4 = z2 & (z2 >> 2), z8 = z4 & (z4 >> 4);
+		const uint32_t inbits = (z1 ? 1u : 0u) + (z2 ? 1u : 0u) + (z4 ? 1u : 0u) + (z8 ? 1u : 0u);
+		const uint32_t fbits = bitlen(gfirst);
+		uint32_t indnbits = row_max(fbits > inbits ? fbits : inbits); // bit length of the longest gap
+		// 256 positions hold at most one gap of 128 or more
+		uint32_t indvar = noutL + (indnbits == 8u ? 1u : 0u);
+		indnbits = indnbits ? indnbits : 1u;
+		const uint4 ci = wt[indnbits];
+		const uint32_t indpck = 16u * __umulhi(noutL + ci.x - 1u, ci.y);
+		const uint32_t ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
+		const uint32_t idata = indpck < indvar ? indpck : indvar;
+		const uint32_t required = fixedL + idata;
+		if (tryit && required < best) {
+			best = required;
+			const uint32_t xm = par.z >> 24;
+			sel.encoding = OROCH_BITPFR;
+			sel.origin = mn;
+			sel.nbits = bL;
+			sel.noutliers = noutL;
+			sel.venc = (par.z >> 16) & 0xffu;
+			sel.vnbits = nbmax - bL;
+			sel.ienc = ienc;
+			sel.inbits = ienc == OROCH_BITPCK ? indnbits : 0u;
+			sel.metaspace = 1 + basic_meta + xm;
+			sel.dataspace = required - basic_meta - xm;
+		}
+	}
+	if (constant) {
+		sel.encoding = OROCH_NAUGHT;
+		sel.nbits = 0;
+		sel.origin = mn;
+		sel.metaspace = 1 + vo;
+		sel.dataspace = 0;
+		sel.noutliers = 0;
+		sel.ienc = sel.venc = OROCH_NORMAL;
+		sel.inbits = sel.vnbits = 0;
+	}
+}
+
+__device__ __forceinline__ uint32_t stream_size(const quad_selection &sel)
+{
+	return (((sel.metaspace + 7u) & ~7u) + sel.dataspace + 15u) & ~15u;
+}
+
+// The descriptor halves in put_desc's layout.
+__device__ __forceinline__ void desc_words(const quad_selection &sel, uint4 &da, uint4 &db)
+{
+	da = make_uint4(sel.origin, 0u, sel.dataspace, stream_size(sel));
+	db = make_uint4(sel.metaspace | (sel.noutliers << 16),
+			uint32_t(BLOCK) | (sel.encoding << 16) | (sel.nbits << 24),
+			sel.ienc | (sel.inbits << 8) | (sel.venc << 16) | (sel.vnbits << 24), 0u);
+}
+
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select_quad(const typename E::S *__restrict__ src,
+								      size_t n, size_t nblocks,
+								      oroch_block_desc *__restrict__ desc,
+								      uint32_t *__restrict__ sizes)
+{
+	using C = typename E::C;
+	__shared__ __attribute__((aligned(16))) uint32_t hqs[WAVES_PER_WG][QUAD * HQ_DWORDS];
+	__shared__ __attribute__((aligned(16))) uint32_t nos[WAVES_PER_WG][QUAD * NO_DWORDS];
+	__shared__ __attribute__((aligned(16))) uint4 pws[WAVES_PER_WG][QUAD * PW_ENTRIES];
+	__shared__ uint4 wt[65];
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	load_width_table(wt);
+	const lane_consts lc = make_lane_consts(wt, lane);
+	const size_t nquads = (nblocks + QUAD - 1) / QUAD;
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
+	for (size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave; q < nquads; q += stride) {
+		const size_t blk0 = q * QUAD;
+		if (blk0 + QUAD <= nblocks && (blk0 + QUAD) * BLOCK <= n) {
+			const int g = lane / GROUP, sub = lane % GROUP;
+			const size_t blk = blk0 + size_t(g);
+			C v[VPQ];
+			load16<E>(src + blk * BLOCK + size_t(sub) * VPQ, v);
+			quad_selection sel;
+			select_quad<E>(v, lane, hqs[wave], nos[wave], pws[wave], wt, sel);
+			uint4 da, db;
+			desc_words(sel, da, db);
+			if (desc && sub < 2)
+				reinterpret_cast<uint4 *>(desc + blk)[sub] = sub ? db : da;
+			if (sizes && sub == 0)
+				sizes[blk] = da.w;
+		} else {
+			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
+				const size_t blk = blk0 + size_t(b);
+				const int nv = block_count(n, blk);
+				C v[VPL];
+				load_block<E>(src, blk * BLOCK, nv, lane, v);
+				selection<C> sel;
+				select_any<E>(v, nv, lane, hqs[wave], wt, lc, sel);
+				if (lane == 0) {
+					if (desc)
+						put_desc(&desc[blk], sel, nv);
+					if (sizes)
+						sizes[blk] = stream_size(sel);
+				}
+				wave_sync();
+			}
+		}
+		wave_sync();
+	}
+}
+
+} // namespace oroch_hip
