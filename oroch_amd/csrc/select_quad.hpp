@@ -202,6 +202,7 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	const uint32_t basic_meta = 1 + vo;
 	uint4 *pwg = pw + g * PW_ENTRIES;
 	bool candA, candB;
+	uint32_t estA, estB;
 	{
 		const bool active = bA < nbmax && dA != 0;
 		const uint32_t xmeta = 2 + (noutA < 128u ? 1u : 2u);
@@ -212,7 +213,8 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint32_t indmin = noutA > 128u ? 32u : 16u; // min(pck(nout, 1), 256), nout in 1..255
 		const uint32_t fixed = basic_meta + xmeta + wt[bA].w + vdata;
 		const uint32_t est = fixed + indmin;
-		candA = active && est < best;
+		candA = active;
+		estA = est;
 		pwg[bA] = make_uint4(est, fixed, noutA | (venc << 16) | (xmeta << 24), 0);
 	}
 	{
@@ -225,7 +227,8 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint32_t indmin = noutB > 128u ? 32u : 16u;
 		const uint32_t fixed = basic_meta + xmeta + wt[bB <= 32u ? bB : 32u].w + vdata;
 		const uint32_t est = fixed + indmin;
-		candB = bB <= 32u && active && est < best;
+		candB = bB <= 32u && active;
+		estB = est;
 		pwg[bB <= 32u ? bB : 33u] = make_uint4(est, fixed, noutB | (venc << 16) | (xmeta << 24), 0);
 	}
 	candA = candA && !constant;
@@ -235,16 +238,22 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	// Replay of the reference's ascending loop, all four blocks in step: each
 	// group takes its narrowest remaining candidate.  `best` only shrinks, so
 	// a width that failed the gate (:327-335) against the initial value fails later.
-	uint32_t cands = group_bits(__ballot(candA), g) | (group_bits(__ballot(candB), g) << 16); // bit b - 1
-	while (__ballot(cands != 0) != 0) {
-		const bool live = cands != 0;
+	// A width whose estimate is not below `best` fails the gate now and, as
+	// `best` only shrinks, ever after: each round a group moves straight on to
+	// its narrowest remaining width that passes.
+	for (;;) {
+		candA = candA && estA < best;
+		candB = candB && estB < best;
+		const uint64_t ballA = __ballot(candA), ballB = __ballot(candB);
+		if ((ballA | ballB) == 0)
+			break;
+		const uint32_t cands = group_bits(ballA, g) | (group_bits(ballB, g) << 16); // bit b - 1
+		const bool tryit = cands != 0;
 		const uint32_t bL = uint32_t(__builtin_ctz(cands | 0x80000000u)) + 1u;
-		cands &= cands - 1u;
-		const uint4 par = pwg[live ? bL : 1u];
-		const uint32_t estL = par.x, fixedL = par.y, noutL = par.z & 0xffffu;
-		const bool tryit = live && estL < best;
-		if (__ballot(tryit) == 0)
-			continue;
+		candA = candA && bA != bL;
+		candB = candB && bB != bL;
+		const uint4 par = pwg[tryit ? bL : 1u];
+		const uint32_t fixedL = par.y, noutL = par.z & 0xffffu;
 		// My exceptions at this width, bit i for value i: bit length above bL,
 		// i.e. fewer than 32 - bL leading zeros (a zero delta reads as 127).
 		const uint32_t thr = (32u - bL) * 0x01010101u;
