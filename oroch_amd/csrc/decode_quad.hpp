@@ -126,19 +126,54 @@ __device__ __forceinline__ quad_header parse_header(const uint4 h)
 	return r;
 }
 
-// Lane p, p + 64, ... unpacks packed word p of the quad: word j of block gp.
+// The blocks of a quad that share a width form a class (a 4-bit mask, uniform);
+// rank_to_group() lists its members in ascending order.
+struct quad_class
+{
+	uint32_t count;   // blocks in the class
+	uint32_t member0, member1, member2, member3;
+};
+
+__device__ __forceinline__ quad_class make_class(uint32_t mask)
+{
+	quad_class c;
+	c.count = uint32_t(__builtin_popcount(mask));
+	uint32_t m = mask | 0x10u;
+	c.member0 = uint32_t(__builtin_ctz(m)) & 3u;
+	m = (m & (m - 1u)) | 0x10u;
+	c.member1 = uint32_t(__builtin_ctz(m)) & 3u;
+	m = (m & (m - 1u)) | 0x10u;
+	c.member2 = uint32_t(__builtin_ctz(m)) & 3u;
+	m = (m & (m - 1u)) | 0x10u;
+	c.member3 = uint32_t(__builtin_ctz(m)) & 3u;
+	return c;
+}
+
+// Packed word p of a class is word j of its rank-th block; NBLK words per block.
+template <uint32_t NBLK>
+__device__ __forceinline__ void class_word(const quad_class &c, uint32_t p, uint32_t &gp, uint32_t &j)
+{
+	const uint32_t rank = (p >= NBLK ? 1u : 0u) + (p >= 2 * NBLK ? 1u : 0u) + (p >= 3 * NBLK ? 1u : 0u);
+	j = p - rank * NBLK;
+	gp = rank == 0 ? c.member0 : rank == 1 ? c.member1 : rank == 2 ? c.member2 : c.member3;
+}
+
+// Lane p, p + 64, ... unpacks packed word p of the class.
 template <typename E, int NB>
-__device__ __forceinline__ void unpack_quad_words(const uint8_t *qb, uint32_t data_at, int lane,
-						  typename E::C *slots)
+__device__ __forceinline__ void unpack_quad_words(const quad_class &c, const uint8_t *qb, uint32_t data_at,
+						  int lane, typename E::C *slots)
 {
 	using C = typename E::C;
 	constexpr uint32_t NBLK = (BLOCK + 128 / NB - 1) / (128 / NB); // packed words per block
-	constexpr uint32_t P = QUAD * NBLK;
+	const uint32_t P = c.count * NBLK;
+	asm volatile("" : "+v"(lane)); // keep lane arithmetic of every width out of the callers' loops
 #pragma unroll
-	for (uint32_t r = 0; r < (P + WAVE - 1) / WAVE; r++) {
+	for (uint32_t r = 0; r < (QUAD * NBLK + WAVE - 1) / WAVE; r++) {
 		const uint32_t p = uint32_t(lane) + r * WAVE;
-		const uint32_t gp = (p >= NBLK ? 1u : 0u) + (p >= 2 * NBLK ? 1u : 0u) + (p >= 3 * NBLK ? 1u : 0u);
-		const uint32_t j = p - gp * NBLK;
+		if (r * WAVE >= P)
+			break;
+		uint32_t gp, j;
+		class_word<NBLK>(c, p, gp, j);
 		// data_at of block gp lives in the lanes of group gp
 		const uint32_t at = lane_gather(data_at, int(gp * GROUP));
 		if (p < P) {
@@ -151,25 +186,32 @@ __device__ __forceinline__ void unpack_quad_words(const uint8_t *qb, uint32_t da
 }
 
 template <typename E, int LO, int HI>
-__device__ __forceinline__ void unpack_quad_dispatch(uint32_t nb, const uint8_t *qb, uint32_t data_at,
-						     int lane, typename E::C *slots)
+__device__ __forceinline__ void unpack_quad_dispatch(uint32_t nb, const quad_class &c, const uint8_t *qb,
+						     uint32_t data_at, int lane, typename E::C *slots)
 {
 	if constexpr (LO == HI) {
-		unpack_quad_words<E, LO>(qb, data_at, lane, slots);
+		unpack_quad_words<E, LO>(c, qb, data_at, lane, slots);
 	} else {
 		constexpr int MID = (LO + HI) / 2;
 		if (nb <= uint32_t(MID))
-			unpack_quad_dispatch<E, LO, MID>(nb, qb, data_at, lane, slots);
+			unpack_quad_dispatch<E, LO, MID>(nb, c, qb, data_at, lane, slots);
 		else
-			unpack_quad_dispatch<E, MID + 1, HI>(nb, qb, data_at, lane, slots);
+			unpack_quad_dispatch<E, MID + 1, HI>(nb, c, qb, data_at, lane, slots);
 	}
 }
 
-// Tries the four-block path on the bytes staged in qbuf (block g at byte
-// rel[g], rel in lanes 0..4).  Returns false, having changed nothing that
-// matters, if the quad does not qualify.
+// One bit per group from a ballot of a group-uniform condition.
+__device__ __forceinline__ uint32_t group_mask(uint64_t ballot)
+{
+	return (uint32_t(ballot) & 1u) | ((uint32_t(ballot) >> 15) & 2u) | ((uint32_t(ballot >> 32) & 1u) << 2) |
+	       ((uint32_t(ballot >> 32) >> 13) & 8u);
+}
+
+// Decodes those blocks of the quad staged in qbuf (block g at byte rel[g], rel
+// in lanes 0..4) that qualify for the four-block path and returns them as a
+// bit mask; the caller does the others one by one.
 template <typename E>
-__device__ __forceinline__ bool decode_quad_fast(const uint32_t *qbuf, uint32_t qbytes, uint32_t rel,
+__device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint32_t qbytes, uint32_t rel,
 						  int lane, typename E::C *slots, uint8_t *ends,
 						  const uint4 *wt, typename E::S *dst, size_t base)
 {
@@ -196,11 +238,11 @@ __device__ __forceinline__ bool decode_quad_fast(const uint32_t *qbuf, uint32_t 
 	// parts, each either bit-packed or as varints.  One exception per lane
 	// and round; varints are located through a 64-byte window, which holds
 	// at least 16 of them.
-	const bool has_exc = m.enc == OROCH_BITPFR;
+	const bool is_pfr = m.enc == OROCH_BITPFR;
 	const uint4 iw = wt[m.inb && m.inb <= 32u ? m.inb : 1u], vw = wt[m.vnb && m.vnb <= 32u ? m.vnb : 1u];
 	const uint32_t ilen_pck = 16u * __umulhi(m.nout + iw.x - 1u, iw.y); // bitpck.h:61-71
 	const uint32_t scan_rel = list_at + (m.inb ? ilen_pck : 0u);        // where varints start
-	if (has_exc) {
+	if (is_pfr) {
 		ok = ok && m.nout >= 1 && m.nout <= uint32_t(BLOCK) && m.inb <= 32u && m.vnb <= uint32_t(E::W);
 		if (!m.inb || !m.vnb)
 			ok = ok && m.nout <= QUAD_MAX_EXC;
@@ -209,14 +251,18 @@ __device__ __forceinline__ bool decode_quad_fast(const uint32_t *qbuf, uint32_t 
 		else
 			ok = ok && scan_rel + 16u <= len;
 	}
-	const uint32_t nb_u = uniform(nb);
-	ok = ok && nb == nb_u;
-	const uint64_t all = __ballot(ok);
-	if ((uint32_t(all) & uint32_t(all >> 32)) != 0xffffffffu)
-		return false;
+	const uint32_t fast = group_mask(__ballot(ok));
+	if (fast == 0)
+		return 0;
+	// blocks of one width are unpacked together
+	for (uint32_t left = fast; left;) {
+		const uint32_t nb_u = read_lane(nb, int(__builtin_ctz(left)) * GROUP);
+		const uint32_t cls = group_mask(__ballot(ok && nb == nb_u));
+		unpack_quad_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, make_class(cls), qb, r0 + m.doff, lane, slots);
+		left &= ~cls;
+	}
 
-	unpack_quad_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, qb, r0 + m.doff, lane, slots);
-
+	const bool has_exc = ok && m.enc == OROCH_BITPFR;
 	if (__ballot(has_exc) != 0) {
 		const uint32_t lb = r0 + list_at;      // index list; a multiple of 8
 		const uint32_t sb = r0 + scan_rel;     // first varint, if any list has them
@@ -272,7 +318,7 @@ __device__ __forceinline__ bool decode_quad_fast(const uint32_t *qbuf, uint32_t 
 			const uint32_t pos = incl - 1u;
 			const bool hit = active && pos < uint32_t(BLOCK);
 			// lanes with nothing to patch OR zero into a spare slot
-			atomicOr(&mine[hit ? pos : uint32_t(SLOT_STRIDE - 1)], hit ? C(hi << nb_u) & E::MASK : C(0));
+			atomicOr(&mine[hit ? pos : uint32_t(SLOT_STRIDE - 1)], hit ? C(hi << (nb & 31u)) & E::MASK : C(0));
 		}
 	}
 	wave_sync();
@@ -281,6 +327,8 @@ __device__ __forceinline__ bool decode_quad_fast(const uint32_t *qbuf, uint32_t 
 	// block s come from the first lane of its group
 #pragma unroll
 	for (int s = 0; s < QUAD; s++) {
+		if (!((fast >> s) & 1u))
+			continue;
 		const uint32_t origin = read_lane(m.origin, s * GROUP);
 		const uint32_t enc = read_lane(m.enc, s * GROUP);
 		const uint4 q = *reinterpret_cast<const uint4 *>(&slots[s * SLOT_STRIDE + lane * VPL]);
@@ -290,7 +338,7 @@ __device__ __forceinline__ bool decode_quad_fast(const uint32_t *qbuf, uint32_t 
 			v[i] = enc == OROCH_BITPCK ? unzz<E>(v[i] & E::MASK) : C((v[i] + origin) & E::MASK);
 		store_block<E>(dst, base + size_t(s) * BLOCK, BLOCK, lane, v);
 	}
-	return true;
+	return fast;
 }
 
 #ifdef OROCH_EXP_COUNT
@@ -379,7 +427,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 
 		const size_t blk0 = q * QUAD;
 		const size_t base = blk0 * BLOCK;
-		bool done = false;
+		uint32_t done = 0;
 #ifndef OROCH_EXP_NOFAST
 		if (blk0 + QUAD <= nblocks && base + size_t(QUAD) * BLOCK <= n)
 #else
@@ -388,14 +436,16 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 			done = decode_quad_fast<E>(qbuf, total0, rel0, lane, slots, endss[wave], wt, dst, base);
 #ifdef OROCH_EXP_COUNT
 		if (lane == 0)
-			atomicAdd(&g_quad_count[done ? 0 : 1], 1ull);
+			atomicAdd(&g_quad_count[done == 15u ? 0 : 1], 1ull);
 #endif
 #ifdef OROCH_EXP_NOSLOW
-		done = true;
+		done = 15u;
 #endif
-		if (!done) {
-			// block by block, from the same staged bytes
+		if (done != 15u) {
+			// the others one by one, from the same staged bytes
 			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
+				if ((done >> b) & 1u)
+					continue;
 				const uint32_t at = read_lane(rel0, b), end = read_lane(rel0, b + 1);
 				const uint32_t len = end > at ? end - at : 0u;
 				const int nv = block_count(n, blk0 + size_t(b));

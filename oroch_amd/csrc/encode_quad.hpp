@@ -64,20 +64,23 @@ __device__ __forceinline__ void load16(const typename E::S *p, typename E::C (&v
 	}
 }
 
-// Lane p, p + 64, ... packs word p of the quad (word j of block gp) from the
-// slots and stores it at its place in the stream.
+// Lane p, p + 64, ... packs word p of a class of blocks (see class_word) from
+// the slots and stores it at its place in the stream.
 template <typename E, int NB>
-__device__ __forceinline__ void pack_quad_words(const typename E::C *slots, uint32_t data_at, int lane,
-						uint8_t *out)
+__device__ __forceinline__ void pack_quad_words(const quad_class &c, const typename E::C *slots,
+						uint32_t data_at, int lane, uint8_t *out)
 {
 	using C = typename E::C;
 	constexpr uint32_t NBLK = (BLOCK + 128 / NB - 1) / (128 / NB);
-	constexpr uint32_t P = QUAD * NBLK;
+	const uint32_t P = c.count * NBLK;
+	asm volatile("" : "+v"(lane)); // keep lane arithmetic of every width out of the callers' loops
 #pragma unroll
-	for (uint32_t r = 0; r < (P + WAVE - 1) / WAVE; r++) {
+	for (uint32_t r = 0; r < (QUAD * NBLK + WAVE - 1) / WAVE; r++) {
 		const uint32_t p = uint32_t(lane) + r * WAVE;
-		const uint32_t gp = (p >= NBLK ? 1u : 0u) + (p >= 2 * NBLK ? 1u : 0u) + (p >= 3 * NBLK ? 1u : 0u);
-		const uint32_t j = p - gp * NBLK;
+		if (r * WAVE >= P)
+			break;
+		uint32_t gp, j;
+		class_word<NBLK>(c, p, gp, j);
 		const uint32_t at = lane_gather(data_at, int(gp * GROUP));
 		if (p < P) {
 			uint32_t w[4];
@@ -88,25 +91,26 @@ __device__ __forceinline__ void pack_quad_words(const typename E::C *slots, uint
 }
 
 template <typename E, int LO, int HI>
-__device__ __forceinline__ void pack_quad_dispatch(uint32_t nb, const typename E::C *slots,
-						   uint32_t data_at, int lane, uint8_t *out)
+__device__ __forceinline__ void pack_quad_dispatch(uint32_t nb, const quad_class &c,
+						   const typename E::C *slots, uint32_t data_at, int lane,
+						   uint8_t *out)
 {
 	if constexpr (LO == HI) {
-		pack_quad_words<E, LO>(slots, data_at, lane, out);
+		pack_quad_words<E, LO>(c, slots, data_at, lane, out);
 	} else {
 		constexpr int MID = (LO + HI) / 2;
 		if (nb <= uint32_t(MID))
-			pack_quad_dispatch<E, LO, MID>(nb, slots, data_at, lane, out);
+			pack_quad_dispatch<E, LO, MID>(nb, c, slots, data_at, lane, out);
 		else
-			pack_quad_dispatch<E, MID + 1, HI>(nb, slots, data_at, lane, out);
+			pack_quad_dispatch<E, MID + 1, HI>(nb, c, slots, data_at, lane, out);
 	}
 }
 
 // da, db: the two halves of this lane's block descriptor (put_desc layout);
-// off: the block's stream offset.  Returns false, with nothing written, if the
-// quad does not qualify.
+// off: the block's stream offset.  Encodes the blocks of the quad that qualify
+// and returns them as a bit mask; the caller does the others one by one.
 template <typename E>
-__device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], const uint4 da,
+__device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VPQ], const uint4 da,
 						  const uint4 db, uint64_t off, int lane,
 						  typename E::C *slots, uint8_t *tails, uint8_t *heads,
 						  const uint4 *wt, uint8_t *dst)
@@ -128,11 +132,9 @@ __device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], 
 	const uint32_t list_at = doff + pck;
 	bool ok = (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) && width_ok &&
 		  dataspace >= pck && size >= list_at && size - list_at <= uint32_t(TAIL_BYTES);
-	const uint32_t nb_u = uniform(nb);
-	ok = ok && nb == nb_u;
-	const uint64_t all = __ballot(ok);
-	if ((uint32_t(all) & uint32_t(all >> 32)) != 0xffffffffu)
-		return false;
+	const uint32_t fast = group_mask(__ballot(ok));
+	if (fast == 0)
+		return 0;
 
 	// stream positions relative to the quad's first block
 	const uint64_t start = uniform(off);
@@ -142,7 +144,7 @@ __device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], 
 	// deltas (or zigzag images) of all values into the slots, in full: the
 	// packer cuts them to the width, the exception lists need the rest
 	C *mine = slots + g * SLOT_STRIDE;
-	const bool has_exc = enc == OROCH_BITPFR;
+	const bool has_exc = ok && enc == OROCH_BITPFR;
 	const bool zig = E::sgn && enc == OROCH_BITPCK;
 	const C org = enc == OROCH_BITPCK ? C(0) : origin;
 	C u[VPQ];
@@ -168,14 +170,20 @@ __device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], 
 	if (__ballot(has_exc) != 0) {
 #pragma unroll
 		for (int i = 0; i < VPQ; i++) {
-			const uint32_t hi = nb_u >= 32u ? 0u : uint32_t(u[i] >> nb_u);
+			const uint32_t hi = uint32_t(u[i] >> (nb & 31u));
 			m |= (hi ? 1u : 0u) << i;
 		}
-		m = has_exc ? m : 0u;
+		m = has_exc && nb < 32u ? m : 0u;
 	}
 	wave_sync();
 
-	pack_quad_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, slots, rel + doff, lane, out);
+	// blocks of one width are packed together
+	for (uint32_t left = fast; left;) {
+		const uint32_t nb_u = read_lane(nb, int(__builtin_ctz(left)) * GROUP);
+		const uint32_t cls = group_mask(__ballot(ok && nb == nb_u));
+		pack_quad_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, make_class(cls), slots, rel + doff, lane, out);
+		left &= ~cls;
+	}
 
 	// metadata, integer_codec.h:128-151, 177-182, 196-204: lane `sub` makes
 	// byte `sub` of the (at most 11-byte) header
@@ -209,7 +217,7 @@ __device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], 
 		uint8_t *head = heads + g * 16;
 		head[sub] = uint8_t(byte);
 		wave_sync();
-		if (uint32_t(sub) * 8u < doff)
+		if (ok && uint32_t(sub) * 8u < doff)
 			*reinterpret_cast<uint2 *>(out + rel + sub * 8) = *reinterpret_cast<const uint2 *>(head + sub * 8);
 	}
 
@@ -232,7 +240,7 @@ __device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], 
 					const int pos = sub * VPQ + int(__builtin_ctz(mm));
 					const uint32_t gap = uint32_t(pos - prev - 1);
 					prev = pos;
-					const C hi = mine[pos] >> nb_u;
+					const C hi = mine[pos] >> nb;
 					ib += gap >= 128u ? 2u : 1u;
 					vb += vsp(hi);
 					mm &= mm - 1u;
@@ -252,7 +260,7 @@ __device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], 
 					const int pos = sub * VPQ + int(__builtin_ctz(mm));
 					const uint32_t gap = uint32_t(pos - prev - 1);
 					prev = pos;
-					const C hi = mine[pos] >> nb_u;
+					const C hi = mine[pos] >> nb;
 					if (ienc == OROCH_BITPCK) {
 						const uint32_t bk = __umulhi(r, iw.y);
 						lds_or_bits(tail32, bk * 128u + (r - bk * iw.x) * inb, gap);
@@ -275,9 +283,11 @@ __device__ __forceinline__ bool encode_quad_fast(const typename E::C (&v)[VPQ], 
 	}
 	wave_sync();
 	// lists and the zero padding up to the block's 16-byte boundary
-	for (uint32_t k = uint32_t(sub) * 8u; k < size - list_at; k += GROUP * 8u)
-		*reinterpret_cast<uint2 *>(out + rel + list_at + k) = *reinterpret_cast<const uint2 *>(tail + k);
-	return true;
+	if (ok) {
+		for (uint32_t k = uint32_t(sub) * 8u; k < size - list_at; k += GROUP * 8u)
+			*reinterpret_cast<uint2 *>(out + rel + list_at + k) = *reinterpret_cast<const uint2 *>(tail + k);
+	}
+	return fast;
 }
 
 template <typename E>
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode_quad(const typena
 	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
 	for (size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave; q < nquads; q += stride) {
 		const size_t blk0 = q * QUAD;
-		bool done = false;
+		uint32_t done = 0;
 		if (blk0 + QUAD <= nblocks && (blk0 + QUAD) * BLOCK <= n) {
 			const size_t blk = blk0 + size_t(lane / GROUP);
 			C v[VPQ];
@@ -310,8 +320,10 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode_quad(const typena
 			done = encode_quad_fast<E>(v, da, db, off, lane, slotss[wave], tailss[wave], headss[wave],
 						   wt, dst);
 		}
-		if (!done) {
+		if (done != 15u) {
 			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
+				if ((done >> b) & 1u)
+					continue;
 				const size_t blk = blk0 + size_t(b);
 				const int nv = block_count(n, blk);
 				C v[VPL];

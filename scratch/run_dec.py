@@ -6,8 +6,14 @@ import oroch_amd
 from bench import gen_outlier_mix_torch
 n = 1 << int(os.environ.get("LOG2N", "26"))
 x = gen_outlier_mix_torch(n, 3, "cuda")
+if os.environ.get("KIND") == "uniform":
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import devgen
+    x = devgen.uniform_bits(n, torch.int32, 3, int(os.environ.get("BODY", "13")), torch.device("cuda", 0))
 enc = oroch_amd.GroupEncoder(np.int32, n, x.device)
 enc.encode(x)
+d = oroch_amd.group_select(x[:4096])
+print("first descs", d[:4])
 back = torch.empty_like(x)
 torch.cuda.synchronize()
 for path in sys.argv[1:]:
