@@ -105,6 +105,19 @@ def cpu_baseline(log2n, seed):
                       "(encode %.2fs, decode %.2fs)" % (log2n, t1 - t0, t2 - t1)}
 
 
+def measured_traffic(kernel, log2n):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3
+    cannot run inside this process); only valid for the workload they were
+    collected on."""
+    path = os.path.join(ROOT, "profiles", "traffic_int32_2p30.json")
+    if log2n != 30 or not os.path.exists(path):
+        return None
+    k = json.load(open(path)).get("kernels", {})
+    names = {"select": "k_select_quad", "encode": "k_encode_quad", "decode": "k_decode_quad"}
+    rec = k.get(names.get(kernel, ""))
+    return rec["total_bytes"] if rec else None
+
+
 def end_to_end(x_dev, log2n):
     """Host buffer -> pinned staging -> device encode -> host stream, and back."""
     import ctypes as C
@@ -258,7 +271,7 @@ def main():
             "kernel_ms": kern,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": measured_traffic(dominant, args.log2n),
                          "algorithmic_bytes_per_launch": algo[dominant],
                          "encode_path": {"ms": enc_path_ms, "algorithmic_bytes": raw + total,
                                          "frac": (raw + total) / (enc_path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -364,7 +364,11 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 	constexpr uint32_t QBYTES = QUAD * IMG;
 	constexpr int NCH = int((QBYTES + 1023) / 1024);
 	constexpr int NPRE = NCH < 3 ? NCH : 3;
+#ifdef OROCH_EXP_SMALLQ
+	__shared__ __attribute__((aligned(16))) uint32_t qbufs[WAVES_PER_WG][QBYTES / 8 + 24];
+#else
 	__shared__ __attribute__((aligned(16))) uint32_t qbufs[WAVES_PER_WG][QBYTES / 4 + 24];
+#endif
 	__shared__ __attribute__((aligned(16))) C slotss[WAVES_PER_WG][QUAD * SLOT_STRIDE];
 	__shared__ __attribute__((aligned(16))) uint8_t endss[WAVES_PER_WG][QUAD * ENDS];
 	__shared__ uint4 wt[65];

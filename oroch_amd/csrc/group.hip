@@ -1217,7 +1217,7 @@ __device__ __forceinline__ uint64_t hdr_varint(uint64_t h0, uint64_t h1, uint32_
 
 // Decodes the block whose image (len bytes) sits in `img`.  FULL: 256 values.
 template <typename E, bool FULL>
-__device__ void decode_block(uint32_t *img, uint32_t len, int nv, int lane, typename E::C *val,
+__device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv, int lane, typename E::C *val,
 			     typename E::C *hv, uint32_t *gp, const uint4 *wt, typename E::C (&v)[VPL])
 {
 	using C = typename E::C;

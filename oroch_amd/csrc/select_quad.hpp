@@ -356,8 +356,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select_quad(const typena
 			select_quad<E>(v, lane, hqs[wave], nos[wave], pws[wave], wt, sel);
 			uint4 da, db;
 			desc_words(sel, da, db);
-			if (desc && sub < 2)
-				reinterpret_cast<uint4 *>(desc + blk)[sub] = sub ? db : da;
+			if (desc && sub < 2) {
+				// (component-wise: selecting whole vectors by lane sends them through scratch)
+				const uint4 half = make_uint4(sub ? db.x : da.x, sub ? db.y : da.y, sub ? db.z : da.z,
+							      sub ? db.w : da.w);
+				reinterpret_cast<uint4 *>(desc + blk)[sub] = half;
+			}
 			if (sizes && sub == 0)
 				sizes[blk] = da.w;
 		} else {
