@@ -341,14 +341,6 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 	return fast;
 }
 
-#ifdef OROCH_EXP_COUNT
-__device__ unsigned long long g_quad_count[2];
-} extern "C" int oroch_debug_quad_count(unsigned long long *out)
-{
-	return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(oroch_hip::g_quad_count), 16));
-}
-namespace oroch_hip {
-#endif
 
 // Persistent wavefronts over quads of blocks; offsets are fetched two quads
 // ahead and the quad's bytes one quad ahead (the first QPRE KiB of them, in
@@ -364,11 +356,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 	constexpr uint32_t QBYTES = QUAD * IMG;
 	constexpr int NCH = int((QBYTES + 1023) / 1024);
 	constexpr int NPRE = NCH < 3 ? NCH : 3;
-#ifdef OROCH_EXP_SMALLQ
-	__shared__ __attribute__((aligned(16))) uint32_t qbufs[WAVES_PER_WG][QBYTES / 8 + 24];
-#else
 	__shared__ __attribute__((aligned(16))) uint32_t qbufs[WAVES_PER_WG][QBYTES / 4 + 24];
-#endif
 	__shared__ __attribute__((aligned(16))) C slotss[WAVES_PER_WG][QUAD * SLOT_STRIDE];
 	__shared__ __attribute__((aligned(16))) uint8_t endss[WAVES_PER_WG][QUAD * ENDS];
 	__shared__ uint4 wt[65];
@@ -432,19 +420,8 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 		const size_t blk0 = q * QUAD;
 		const size_t base = blk0 * BLOCK;
 		uint32_t done = 0;
-#ifndef OROCH_EXP_NOFAST
 		if (blk0 + QUAD <= nblocks && base + size_t(QUAD) * BLOCK <= n)
-#else
-		if (false)
-#endif
 			done = decode_quad_fast<E>(qbuf, total0, rel0, lane, slots, endss[wave], wt, dst, base);
-#ifdef OROCH_EXP_COUNT
-		if (lane == 0)
-			atomicAdd(&g_quad_count[done == 15u ? 0 : 1], 1ull);
-#endif
-#ifdef OROCH_EXP_NOSLOW
-		done = 15u;
-#endif
 		if (done != 15u) {
 			// the others one by one, from the same staged bytes
 			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {

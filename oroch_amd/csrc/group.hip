@@ -249,9 +249,6 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	// integer_codec.h:271-272
 	if (nv < 5)
 		return;
-#ifdef OROCH_EXP_NO_PFR
-	return;
-#endif
 
 	// ---- patched frame of reference, integer_codec.h:280-383 ----
 	// histogram of bit lengths into LDS, then lane l looks after width b = l + 1
@@ -294,9 +291,6 @@ __device__ void select_block(const typename E::C (&v)[VPL], int nv, int lane, ui
 	// Replay of the reference's ascending loop.  `best` only shrinks, so a
 	// width failing the gate (:327-335) against the initial value fails later.
 	uint64_t cand = __ballot(active && est < best);
-#ifdef OROCH_EXP_NO_WALK
-	cand = 0;
-#endif
 	while (cand) {
 		const int L = __builtin_ctzll(cand);
 		cand &= cand - 1;
@@ -976,12 +970,6 @@ __global__ __launch_bounds__(WAVE *FUSED_WAVES) void k_encode_fused(
 	auto count_of = [&](size_t blk) -> int {
 		return blk < nblocks ? block_count(n, blk) : 0;
 	};
-#ifdef OROCH_EXP_STAGGER
-	// spread the workgroups' phases over one tile time so that the tiles of a
-	// round finish in tile order instead of all at once
-	for (unsigned i = 0, e = unsigned(uint64_t(blockIdx.x) * OROCH_EXP_STAGGER / gridDim.x); i < e; i++)
-		__builtin_amdgcn_s_sleep(10);
-#endif
 	typename E::C v[VPL], v1[VPL], v2[VPL];
 	size_t j = 0;
 	load_block<E>(src, block_of(0) * BLOCK, count_of(block_of(0)), lane, v);
@@ -1027,11 +1015,7 @@ __global__ __launch_bounds__(WAVE *FUSED_WAVES) void k_encode_fused(
 			if (lane == 0)
 				state_store(&state[tile], (tile == 0 ? ST_PREFIX : ST_AGG) | tile_bytes);
 			uint64_t exclusive = 0;
-#ifdef OROCH_EXP_NO_LOOKBACK
-			const bool ok = true;
-#else
 			const bool ok = tile == 0 || look_back(state, tile, lane, abort_flag, exclusive);
-#endif
 			if (lane == 0) {
 				if (ok && tile != 0)
 					state_store(&state[tile], ST_PREFIX | (exclusive + tile_bytes));
@@ -1185,10 +1169,6 @@ __device__ uint32_t varint_list_decode(const uint8_t *img8, uint32_t start, uint
 	return pos - start;
 }
 
-#ifdef OROCH_DEBUG_DECODE2
-__device__ uint32_t *g_dbg = nullptr;
-extern "C" __global__ void k_set_dbg(uint32_t *p) { g_dbg = p; }
-#endif
 
 // Byte p (0..15) of a 16-byte header held in two scalar registers.  (Plain
 // variables, not an array: a dynamically indexed private array is moved to
@@ -1242,11 +1222,6 @@ __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv
 		vnb = hdr_byte(h0, h1, p++);
 	}
 	const uint32_t doff = (p + 7u) & ~7u; // integer_group.h:70-72
-#ifdef OROCH_DEBUG_DECODE
-	if (lane == 0)
-		printf("dec: enc %u nb %u nout %u inb %u vnb %u doff %u len %u nv %d h0 %llx\n", enc, nb, nout, inb,
-		       vnb, doff, len, nv, (unsigned long long) h0);
-#endif
 
 #pragma unroll
 	for (int s = 0; s < VPL; s++)
@@ -1274,11 +1249,7 @@ __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv
 			// lane j unpacks packed block j with compile-time field positions
 			const uint32_t nblk = pck_space(wt, uint32_t(nv), nb) >> 4;
 			// (widths above 32 bits have more than 64 packed blocks)
-#ifdef OROCH_EXP_NOUNPACK
-			for (uint32_t j = uint32_t(lane); j < 0; j += WAVE) {
-#else
 			for (uint32_t j = uint32_t(lane); j < nblk; j += WAVE) {
-#endif
 				const uint2 *q = reinterpret_cast<const uint2 *>(img8 + doff) + j * 2;
 				const uint2 a = q[0], b = q[1];
 				const uint32_t w[4] = {a.x, a.y, b.x, b.y};
@@ -1300,12 +1271,8 @@ __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv
 			}
 		}
 		wave_sync();
-#ifdef OROCH_EXP_NOEXC
-		if (false) {
-#else
 		if (enc == OROCH_BITPFR && nout > 0 && nout <= uint32_t(nv) && vnb <= uint32_t(E::W) &&
 		    inb <= 64) {
-#endif
 			// integer_codec.h:583-609, bitpfr.h:114-124
 			const uint32_t ibase = doff + pck_space(wt, uint32_t(nv), nb);
 			// varint lists are assembled by OR into zeroed LDS slots
@@ -1450,9 +1417,6 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__
 		extent(blk + 2 * stride, off2, end2);
 		resolve(off1, end1, len1);
 		fetch(off1, len1, im1);
-#ifdef OROCH_EXP_SYNCFETCH
-		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
 
 		const size_t base = blk * BLOCK;
 		const int nv = block_count(n, blk);
@@ -1789,13 +1753,6 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 	return rc;
 }
 
-#ifdef OROCH_DEBUG_DECODE2
-extern "C" int oroch_debug_set(uint32_t *p)
-{
-	hipLaunchKernelGGL(k_set_dbg, dim3(1), dim3(1), 0, nullptr, p);
-	return int(hipDeviceSynchronize());
-}
-#endif
 
 extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n,
 				  void *dst, void *stream)
