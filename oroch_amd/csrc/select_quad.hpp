@@ -55,6 +55,24 @@ __device__ __forceinline__ uint32_t group_bits(uint64_t ballot, int g)
 	return (half >> ((g & 1) * 16)) & 0xffffu;
 }
 
+// What a lane needs to know about its two widths, computed once per kernel.
+struct quad_lane_consts
+{
+	uint32_t wA, wB;     // varint bytes of a value of bit length sub + 1, sub + 17
+	uint32_t pckA, pckB; // bitpck space of 256 values at those widths
+};
+
+__device__ __forceinline__ quad_lane_consts make_quad_lane_consts(const uint4 *wt, int lane)
+{
+	const uint32_t sub = uint32_t(lane % GROUP);
+	quad_lane_consts c;
+	c.wA = vsp_bits(sub + 1u);
+	c.wB = vsp_bits(sub + 17u);
+	c.pckA = wt[sub + 1u].w;
+	c.pckB = wt[sub + 17u].w;
+	return c;
+}
+
 // Group-uniform outcome of selection, one copy per lane.
 struct quad_selection
 {
@@ -65,7 +83,8 @@ struct quad_selection
 // owned by this wavefront.
 template <typename E>
 __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int lane, uint32_t *hq,
-					    uint32_t *no, uint4 *pw, const uint4 *wt, quad_selection &sel)
+					    uint32_t *no, uint4 *pw, const uint4 *wt, const quad_lane_consts &lc,
+					    quad_selection &sel)
 {
 	using C = typename E::C;
 	static_assert(sizeof(C) == 4, "element types up to 32 bits");
@@ -140,7 +159,7 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	const bool constant = zero_d == uint32_t(BLOCK); // integer_codec.h:255-264, applied at the end
 
 	// the two varint footprints, integer_codec.h:483-489, from the histograms
-	const uint32_t wA = vsp_bits(bA), wB = vsp_bits(bB);
+	const uint32_t wA = lc.wA, wB = lc.wB;
 	const uint32_t t = row_sum(dA * wA + dB * wB + ((zA * wA + zB * wB) << 16));
 	const uint32_t vfs = (t & 0xffffu) + zero_d, vis = (t >> 16) + zero_z;
 	// widest delta and widest zigzag image
@@ -197,8 +216,6 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	// varint bytes of the high parts: each value of bit length k > b costs
 	// ceil((k - b) / 7), i.e. the sum over j >= 0 of nout(b + 7j) (:308-312)
 	const uint32_t valvarA = noutA + nog[bA + 6] + nog[bA + 13] + nog[bA + 20] + nog[bA + 27];
-	const uint32_t valvarB = noutB + nog[(bB + 6) & 63] + nog[(bB + 13) & 63] + nog[(bB + 20) & 63] +
-				 nog[(bB + 27) & 63];
 	const uint32_t basic_meta = 1 + vo;
 	uint4 *pwg = pw + g * PW_ENTRIES;
 	bool candA, candB;
@@ -211,25 +228,28 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint32_t venc = valpck < valvarA ? OROCH_BITPCK : OROCH_VARINT;
 		const uint32_t vdata = valpck < valvarA ? valpck : valvarA;
 		const uint32_t indmin = noutA > 128u ? 32u : 16u; // min(pck(nout, 1), 256), nout in 1..255
-		const uint32_t fixed = basic_meta + xmeta + wt[bA].w + vdata;
+		const uint32_t fixed = basic_meta + xmeta + lc.pckA + vdata;
 		const uint32_t est = fixed + indmin;
 		candA = active;
 		estA = est;
 		pwg[bA] = make_uint4(est, fixed, noutA | (venc << 16) | (xmeta << 24), 0);
 	}
-	{
+	candB = false;
+	estB = 0;
+	// widths 17..32 only where some block of the quad has a candidate there
+	if (__ballot(bB < nbmax && dB != 0) != 0) {
 		const bool active = bB < nbmax && dB != 0;
+		const uint32_t valvarB = noutB + nog[bB + 6] + nog[bB + 13] + nog[bB + 20] + nog[bB + 27];
 		const uint32_t xmeta = 2 + (noutB < 128u ? 1u : 2u);
 		const uint4 cm = wt[active ? nbmax - bB : 1u];
 		const uint32_t valpck = 16u * __umulhi(noutB + cm.x - 1u, cm.y);
 		const uint32_t venc = valpck < valvarB ? OROCH_BITPCK : OROCH_VARINT;
 		const uint32_t vdata = valpck < valvarB ? valpck : valvarB;
 		const uint32_t indmin = noutB > 128u ? 32u : 16u;
-		const uint32_t fixed = basic_meta + xmeta + wt[bB <= 32u ? bB : 32u].w + vdata;
-		const uint32_t est = fixed + indmin;
-		candB = bB <= 32u && active;
-		estB = est;
-		pwg[bB <= 32u ? bB : 33u] = make_uint4(est, fixed, noutB | (venc << 16) | (xmeta << 24), 0);
+		const uint32_t fixed = basic_meta + xmeta + lc.pckB + vdata;
+		estB = fixed + indmin;
+		candB = active;
+		pwg[bB] = make_uint4(estB, fixed, noutB | (venc << 16) | (xmeta << 24), 0);
 	}
 	candA = candA && !constant;
 	candB = candB && !constant;
@@ -241,6 +261,7 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	// A width whose estimate is not below `best` fails the gate now and, as
 	// `best` only shrinks, ever after: each round a group moves straight on to
 	// its narrowest remaining width that passes.
+	uint32_t got = 0, gotpar = 0;
 	for (;;) {
 		candA = candA && estA < best;
 		candB = candB && estB < best;
@@ -290,18 +311,23 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint32_t required = fixedL + idata;
 		if (tryit && required < best) {
 			best = required;
-			const uint32_t xm = par.z >> 24;
-			sel.encoding = OROCH_BITPFR;
-			sel.origin = mn;
-			sel.nbits = bL;
-			sel.noutliers = noutL;
-			sel.venc = (par.z >> 16) & 0xffu;
-			sel.vnbits = nbmax - bL;
-			sel.ienc = ienc;
-			sel.inbits = ienc == OROCH_BITPCK ? indnbits : 0u;
-			sel.metaspace = 1 + basic_meta + xm;
-			sel.dataspace = required - basic_meta - xm;
+			got = bL | (ienc == OROCH_BITPCK ? indnbits << 8 : 0u) | (ienc << 16);
+			gotpar = par.z;
 		}
+	}
+	if (got) {
+		// the last width adopted, :365-382
+		const uint32_t bL = got & 0xffu, xm = gotpar >> 24;
+		sel.encoding = OROCH_BITPFR;
+		sel.origin = mn;
+		sel.nbits = bL;
+		sel.noutliers = gotpar & 0xffffu;
+		sel.venc = (gotpar >> 16) & 0xffu;
+		sel.vnbits = nbmax - bL;
+		sel.ienc = got >> 16;
+		sel.inbits = (got >> 8) & 0xffu;
+		sel.metaspace = 1 + basic_meta + xm;
+		sel.dataspace = best - basic_meta - xm;
 	}
 	if (constant) {
 		sel.encoding = OROCH_NAUGHT;
@@ -343,6 +369,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select_quad(const typena
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
 	load_width_table(wt);
 	const lane_consts lc = make_lane_consts(wt, lane);
+	const quad_lane_consts qlc = make_quad_lane_consts(wt, lane);
 	const size_t nquads = (nblocks + QUAD - 1) / QUAD;
 	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
 	for (size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave; q < nquads; q += stride) {
@@ -353,7 +380,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select_quad(const typena
 			C v[VPQ];
 			load16<E>(src + blk * BLOCK + size_t(sub) * VPQ, v);
 			quad_selection sel;
-			select_quad<E>(v, lane, hqs[wave], nos[wave], pws[wave], wt, sel);
+			select_quad<E>(v, lane, hqs[wave], nos[wave], pws[wave], wt, qlc, sel);
 			uint4 da, db;
 			desc_words(sel, da, db);
 			if (desc && sub < 2) {
