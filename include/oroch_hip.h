@@ -229,6 +229,63 @@ int oroch_bitpfr_patch_host(int dtype, void *dst_host, size_t n, uint64_t origin
 			    const uint64_t *indices_host, const uint64_t *values_host,
 			    size_t nexc);
 
+/* ---- serialised container ------------------------------------------------------ */
+
+/*
+ * One self-contained byte string for a compressed array, for files and
+ * network buffers.  The reference has no counterpart: integer_array keeps one
+ * heap buffer per group (integer_array.h:258) and defines no serialised form.
+ *
+ *   [header, 64 bytes]
+ *   [offsets table: (nblocks + 1) x uint64, relative to the first block image]
+ *   [zero pad to a multiple of 16]
+ *   [block images as oroch_group_encode writes them]
+ *
+ * Every block image is byte-identical to integer_group<T>::encode(aligned =
+ * true) of its 256 values and starts at a multiple of 16 bytes, so any range of
+ * blocks can be decoded on its own.
+ */
+typedef struct oroch_container_header {
+	uint8_t magic[8];        /* "OROCHBK1" */
+	uint32_t dtype;          /* dtype code */
+	uint32_t block_values;   /* OROCH_BLOCK_VALUES */
+	uint64_t nvalues;
+	uint64_t nblocks;
+	uint64_t table_offset;   /* 64 */
+	uint64_t stream_offset;  /* align16(64 + 8 * (nblocks + 1)) */
+	uint64_t stream_bytes;   /* length of the block images */
+	uint64_t reserved;       /* 0 */
+} oroch_container_header;
+
+/* Worst-case container bytes for n values. */
+size_t oroch_container_bound(int dtype, size_t n);
+/*
+ * Encodes src[0..n) (device) into a container at dst (device, 16-byte aligned,
+ * oroch_container_bound() bytes).  workspace: oroch_group_workspace() bytes.
+ * Waits for the stream; *total_host receives the container length.
+ */
+int oroch_container_encode(int dtype, const void *src, size_t n, void *dst, size_t dst_capacity,
+			   void *workspace, size_t workspace_bytes, uint64_t *total_host,
+			   void *stream);
+/*
+ * Checks a header (host copy of the container's first 64 bytes) against the
+ * number of bytes at hand; OROCH_E_ARGUMENT if it is not a container this
+ * library wrote or the bytes do not cover it.
+ */
+int oroch_container_check(const oroch_container_header *header_host, size_t container_bytes);
+/*
+ * Decodes blocks [first_block, first_block + nblocks) of the container at src
+ * (device, 16-byte aligned) into dst (device): values first_block * 256 ...
+ * header_host: host copy of the header, as checked by oroch_container_check.
+ */
+int oroch_container_decode(const void *src, const oroch_container_header *header_host,
+			   size_t first_block, size_t nblocks, void *dst, void *stream);
+/* The same with host buffers on both sides (staged through pinned memory). */
+int oroch_container_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
+				size_t dst_capacity, uint64_t *total_host);
+int oroch_container_decode_host(const void *src_host, size_t container_bytes, size_t first_block,
+				size_t nblocks, void *dst_host);
+
 /* ---- diagnostics ---------------------------------------------------------------- */
 
 /*

@@ -22,6 +22,11 @@ from .capi import (  # noqa: F401
     group_bound,
     group_decode,
     group_decode_host,
+    container_decode,
+    container_decode_host,
+    container_encode,
+    container_encode_host,
+    container_header,
     group_encode,
     group_encode_host,
     group_select,

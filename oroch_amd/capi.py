@@ -79,6 +79,12 @@ def _load():
         "oroch_bitpfr_encode_host": (i, [i, vp, sz, u64, u32, vp, vp, vp, vp]),
         "oroch_bitpfr_decode_host": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp]),
         "oroch_bitpfr_patch_host": (i, [i, vp, sz, u64, u32, vp, vp, sz]),
+        "oroch_container_bound": (sz, [i, sz]),
+        "oroch_container_encode": (i, [i, vp, sz, vp, sz, vp, sz, vp, vp]),
+        "oroch_container_check": (i, [vp, sz]),
+        "oroch_container_decode": (i, [vp, vp, sz, sz, vp, vp]),
+        "oroch_container_encode_host": (i, [i, vp, sz, vp, sz, vp]),
+        "oroch_container_decode_host": (i, [vp, sz, sz, sz, vp]),
         "oroch_hip_profile_start": (i, [i]),
         "oroch_hip_profile_stop": (i, [vp, vp]),
     }
@@ -311,4 +317,77 @@ def group_decode_host(stream, offs, n, dtype):
     out = np.empty(n, dtype)
     _check(lib.oroch_group_decode_host(dtype_code(dtype), stream.ctypes.data, offs.ctypes.data, n,
                                        out.ctypes.data))
+    return out
+
+
+# ---- serialised container ------------------------------------------------------------
+
+HEADER_DTYPE = np.dtype([("magic", "S8"), ("dtype", "<u4"), ("block_values", "<u4"), ("nvalues", "<u8"),
+                         ("nblocks", "<u8"), ("table_offset", "<u8"), ("stream_offset", "<u8"),
+                         ("stream_bytes", "<u8"), ("reserved", "<u8")])
+assert HEADER_DTYPE.itemsize == 64
+
+
+def container_encode(x):
+    """x: 1-D CUDA tensor -> uint8 CUDA tensor holding the whole container."""
+    import torch
+
+    code = dtype_code(x.dtype)
+    n = x.numel()
+    bound = lib.oroch_container_bound(code, n)
+    out = torch.empty(bound, dtype=torch.uint8, device=x.device)
+    wsb = lib.oroch_group_workspace(code, n)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+    total = C.c_uint64(0)
+    _check(lib.oroch_container_encode(code, x.data_ptr(), n, out.data_ptr(), bound, ws.data_ptr(), wsb,
+                                      C.byref(total), _stream()))
+    return out[:total.value]
+
+
+def container_header(c):
+    """Header record (numpy, HEADER_DTYPE) of a container held in a CUDA tensor or numpy array."""
+    head = c[:64].cpu().numpy() if hasattr(c, "cpu") else np.ascontiguousarray(c[:64])
+    h = head.view(HEADER_DTYPE)[0]
+    nbytes = c.numel() if hasattr(c, "numel") else c.size
+    _check(lib.oroch_container_check(head.ctypes.data, nbytes))
+    return h
+
+
+def container_decode(c, first_block=0, nblocks=None):
+    """Decodes a block range of a container held in a CUDA uint8 tensor."""
+    import torch
+
+    head = c[:64].cpu().numpy()
+    _check(lib.oroch_container_check(head.ctypes.data, c.numel()))
+    h = head.view(HEADER_DTYPE)[0]
+    if nblocks is None:
+        nblocks = int(h["nblocks"]) - first_block
+    lo = first_block * BLOCK_VALUES
+    hi = min((first_block + nblocks) * BLOCK_VALUES, int(h["nvalues"]))
+    out = torch.empty(max(hi - lo, 0), dtype=_torch_dtype(int(h["dtype"])), device=c.device)
+    _check(lib.oroch_container_decode(c.data_ptr(), head.ctypes.data, first_block, nblocks, out.data_ptr(),
+                                      _stream()))
+    return out
+
+
+def container_encode_host(a):
+    a = np.ascontiguousarray(a)
+    code = dtype_code(a.dtype)
+    bound = lib.oroch_container_bound(code, a.size)
+    out = np.empty(bound, np.uint8)
+    total = C.c_uint64(0)
+    _check(lib.oroch_container_encode_host(code, a.ctypes.data, a.size, out.ctypes.data, bound, C.byref(total)))
+    return out[:total.value].copy()
+
+
+def container_decode_host(c, first_block=0, nblocks=None):
+    c = np.ascontiguousarray(c)
+    _check(lib.oroch_container_check(c.ctypes.data, c.size))
+    h = c[:64].view(HEADER_DTYPE)[0]
+    if nblocks is None:
+        nblocks = int(h["nblocks"]) - first_block
+    lo = first_block * BLOCK_VALUES
+    hi = min((first_block + nblocks) * BLOCK_VALUES, int(h["nvalues"]))
+    out = np.empty(max(hi - lo, 0), DTYPES[int(h["dtype"])])
+    _check(lib.oroch_container_decode_host(c.ctypes.data, c.size, first_block, nblocks, out.ctypes.data))
     return out

@@ -484,3 +484,160 @@ extern "C" int oroch_bitpfr_patch_host(int dtype, void *dst_host, size_t n, uint
 		return rc;
 	return staged_copy(dst_host, out.p, bytes, false, nullptr);
 }
+
+// ---- serialised container ------------------------------------------------------------
+
+namespace {
+
+const uint8_t CONTAINER_MAGIC[8] = {'O', 'R', 'O', 'C', 'H', 'B', 'K', '1'};
+
+size_t container_stream_offset(size_t nblocks)
+{
+	return (sizeof(oroch_container_header) + (nblocks + 1) * sizeof(uint64_t) + 15) & ~size_t(15);
+}
+
+} // namespace
+
+extern "C" size_t oroch_container_bound(int dtype, size_t n)
+{
+	const size_t nblocks = (n + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
+	return container_stream_offset(nblocks) + oroch_group_bound(dtype, n);
+}
+
+extern "C" int oroch_container_encode(int dtype, const void *src, size_t n, void *dst,
+				      size_t dst_capacity, void *workspace, size_t workspace_bytes,
+				      uint64_t *total_host, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (!dst || !total_host || (n && (!src || !workspace)) || (reinterpret_cast<uintptr_t>(dst) & 15u))
+		return OROCH_E_ARGUMENT;
+	if (dst_capacity < oroch_container_bound(dtype, n))
+		return OROCH_E_CAPACITY;
+	const size_t nblocks = (n + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
+	uint8_t *base = static_cast<uint8_t *>(dst);
+	oroch_container_header h;
+	memset(&h, 0, sizeof h);
+	memcpy(h.magic, CONTAINER_MAGIC, sizeof h.magic);
+	h.dtype = uint32_t(dtype);
+	h.block_values = OROCH_BLOCK_VALUES;
+	h.nvalues = n;
+	h.nblocks = nblocks;
+	h.table_offset = sizeof(oroch_container_header);
+	h.stream_offset = container_stream_offset(nblocks);
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	// the pad between the table and the images
+	int rc = int(hipMemsetAsync(base + h.stream_offset - 16, 0, 16, st));
+	if (rc)
+		return rc;
+	uint64_t total = 0;
+	rc = oroch_group_encode(dtype, src, n, base + h.stream_offset, dst_capacity - h.stream_offset,
+				reinterpret_cast<uint64_t *>(base + h.table_offset), workspace, workspace_bytes,
+				&total, stream);
+	if (rc)
+		return rc;
+	h.stream_bytes = total;
+	rc = int(hipMemcpyAsync(base, &h, sizeof h, hipMemcpyHostToDevice, st));
+	if (rc == 0)
+		rc = int(hipStreamSynchronize(st));
+	*total_host = h.stream_offset + total;
+	return rc;
+}
+
+extern "C" int oroch_container_check(const oroch_container_header *h, size_t container_bytes)
+{
+	if (!h || container_bytes < sizeof *h || memcmp(h->magic, CONTAINER_MAGIC, sizeof h->magic) != 0)
+		return OROCH_E_ARGUMENT;
+	if (h->dtype > 7u || h->block_values != OROCH_BLOCK_VALUES || h->reserved != 0)
+		return OROCH_E_ARGUMENT;
+	const uint64_t nblocks = (h->nvalues + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
+	if (h->nblocks != nblocks || h->table_offset != sizeof *h ||
+	    h->stream_offset != container_stream_offset(size_t(nblocks)) || (h->stream_bytes & 15u))
+		return OROCH_E_ARGUMENT;
+	if (h->stream_bytes > container_bytes || h->stream_offset > container_bytes - h->stream_bytes)
+		return OROCH_E_ARGUMENT;
+	return 0;
+}
+
+extern "C" int oroch_container_decode(const void *src, const oroch_container_header *h,
+				      size_t first_block, size_t nblocks, void *dst, void *stream)
+{
+	if (!h || !src || (reinterpret_cast<uintptr_t>(src) & 15u))
+		return OROCH_E_ARGUMENT;
+	int rc = oroch_container_check(h, size_t(h->stream_offset + h->stream_bytes));
+	if (rc)
+		return rc;
+	if (first_block > h->nblocks || nblocks > h->nblocks - first_block)
+		return OROCH_E_ARGUMENT;
+	if (nblocks == 0)
+		return 0;
+	if (!dst)
+		return OROCH_E_ARGUMENT;
+	const uint8_t *base = static_cast<const uint8_t *>(src);
+	const uint64_t lo = uint64_t(first_block) * OROCH_BLOCK_VALUES;
+	uint64_t hi = uint64_t(first_block + nblocks) * OROCH_BLOCK_VALUES;
+	hi = hi < h->nvalues ? hi : h->nvalues;
+	// the table's offsets are relative to the first image, which is what the
+	// decoder adds them to
+	return oroch_group_decode(int(h->dtype), base + h->stream_offset,
+				  reinterpret_cast<const uint64_t *>(base + h->table_offset) + first_block,
+				  size_t(hi - lo), dst, stream);
+}
+
+extern "C" int oroch_container_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
+					   size_t dst_capacity, uint64_t *total_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (!dst_host || !total_host || (n && !src_host))
+		return OROCH_E_ARGUMENT;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t bound = oroch_container_bound(dtype, n);
+	dev_buf in, out, ws;
+	int rc;
+	if ((rc = in.alloc(bytes)) || (rc = out.alloc(bound)) || (rc = ws.alloc(oroch_group_workspace(dtype, n))))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, bytes, true, nullptr)))
+		return rc;
+	uint64_t total = 0;
+	rc = oroch_container_encode(dtype, in.p, n, out.p, bound, ws.p, oroch_group_workspace(dtype, n), &total,
+				    nullptr);
+	if (rc)
+		return rc;
+	*total_host = total;
+	if (total > dst_capacity)
+		return OROCH_E_CAPACITY;
+	return staged_copy(dst_host, out.p, size_t(total), false, nullptr);
+}
+
+extern "C" int oroch_container_decode_host(const void *src_host, size_t container_bytes,
+					   size_t first_block, size_t nblocks, void *dst_host)
+{
+	if (!src_host || container_bytes < sizeof(oroch_container_header))
+		return OROCH_E_ARGUMENT;
+	oroch_container_header h;
+	memcpy(&h, src_host, sizeof h);
+	int rc = oroch_container_check(&h, container_bytes);
+	if (rc)
+		return rc;
+	if (first_block > h.nblocks || nblocks > h.nblocks - first_block)
+		return OROCH_E_ARGUMENT;
+	if (nblocks == 0)
+		return 0;
+	if (!dst_host)
+		return OROCH_E_ARGUMENT;
+	const uint64_t lo = uint64_t(first_block) * OROCH_BLOCK_VALUES;
+	uint64_t hi = uint64_t(first_block + nblocks) * OROCH_BLOCK_VALUES;
+	hi = hi < h.nvalues ? hi : h.nvalues;
+	const size_t out_bytes = size_t(hi - lo) << (h.dtype >> 1);
+	const size_t total = size_t(h.stream_offset + h.stream_bytes);
+	dev_buf in, out;
+	if ((rc = in.alloc(total + 16)) || (rc = out.alloc(out_bytes)))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, total, true, nullptr)))
+		return rc;
+	rc = oroch_container_decode(in.p, &h, first_block, nblocks, out.p, nullptr);
+	if (rc)
+		return rc;
+	return staged_copy(dst_host, out.p, out_bytes, false, nullptr);
+}

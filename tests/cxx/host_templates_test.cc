@@ -10,6 +10,7 @@
 #include <limits>
 #include <vector>
 
+#include <oroch/integer_container.h>
 #include <oroch/integer_group.h>
 
 #include "oroch_oracle.h"
@@ -381,6 +382,44 @@ static void test_blocks()
 	}
 }
 
+// The serialised form: block images equal to integer_group's, any block range
+// decodable on its own, bytes survive a trip through a plain byte vector.
+template <typename T>
+static void test_container()
+{
+	const int dt = oroch::hip::dtype_of<T>();
+	std::vector<T> v;
+	for (int b = 0; b < 40; b++) {
+		const std::vector<T> part = make_block<T>(int(rnd() % 8), b == 39 ? 100 : 256);
+		v.insert(v.end(), part.begin(), part.end());
+	}
+	oroch::integer_container<T> c;
+	c.encode(v.begin(), v.end());
+	REQUIRE(c.nvalues() == v.size() && c.nblocks() == 40);
+	std::vector<uint8_t> want(orc_group_bound(dt, 256) * 41 + 64);
+	std::vector<uint64_t> offs(41);
+	const size_t total = orc_blocks_encode(dt, v.data(), v.size(), 256, 16, want.data(), offs.data());
+	const size_t at = (64 + 8 * 41 + 15) / 16 * 16;
+	REQUIRE(c.bytes().size() == at + total);
+	REQUIRE(std::memcmp(c.bytes().data() + at, want.data(), total) == 0);
+	REQUIRE(std::memcmp(c.bytes().data() + 64, offs.data(), 8 * 41) == 0);
+	oroch::integer_container<T> d(std::vector<uint8_t>(c.bytes()));
+	std::vector<T> back(v.size());
+	d.decode(back.begin(), back.end());
+	REQUIRE(back == v);
+	std::vector<T> some(3 * 256);
+	d.decode_blocks(7, 3, some.begin());
+	REQUIRE(std::equal(some.begin(), some.end(), v.begin() + 7 * 256));
+	bool thrown = false;
+	try {
+		std::vector<uint8_t> cut(c.bytes().begin(), c.bytes().end() - 16);
+		oroch::integer_container<T> e(std::move(cut));
+	} catch (const std::runtime_error &) {
+		thrown = true;
+	}
+	REQUIRE(thrown);
+}
+
 static void test_errors()
 {
 	std::vector<int32_t> v(257, 3);
@@ -417,6 +456,7 @@ static void run_type(const char *name)
 	test_stats_select_group<T>();
 	test_sequences<T>();
 	test_blocks<T>();
+	test_container<T>();
 	std::printf("%-8s ok so far: %d checks, %d failed\n", name, g_checks, g_failed);
 	std::fflush(stdout);
 }

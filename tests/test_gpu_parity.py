@@ -343,3 +343,45 @@ def test_four_block_decoder_paths(hip, oracle, dt, monkeypatch):
     for cut in (256 * 5 + 17, 256 * 2, 255, 1):
         s2, o2 = hip.group_encode(x[:cut])
         assert np.array_equal(host(hip.group_decode(s2, o2, cut, dt)).view(dt), a[:cut])
+
+
+@pytest.mark.parametrize("dt", [np.int16, np.uint32, np.int64])
+def test_serialised_container(hip, oracle, dt):
+    import torch
+
+    rng = np.random.default_rng(99)
+    a = np.concatenate([dg.fuzz_block(rng, dt, 256) for _ in range(300)] + [dg.fuzz_block(rng, dt, 77)])
+    c = hip.container_encode(dev(a))
+    h = hip.container_header(c)
+    nb = 301
+    assert h["magic"] == b"OROCHBK1" and int(h["nvalues"]) == a.size and int(h["nblocks"]) == nb
+    assert int(h["table_offset"]) == 64 and int(h["stream_offset"]) == (64 + 8 * (nb + 1) + 15) // 16 * 16
+    assert c.numel() == int(h["stream_offset"]) + int(h["stream_bytes"])
+    raw = host(c)
+    exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+    table = raw[64:64 + 8 * (nb + 1)].view(np.uint64)
+    assert np.array_equal(table, exp_offs)
+    assert not raw[64 + 8 * (nb + 1):int(h["stream_offset"])].any()
+    assert np.array_equal(raw[int(h["stream_offset"]):], exp)
+    assert np.array_equal(host(hip.container_decode(c)).view(dt), a)
+    # any range of blocks on its own
+    for first, count in ((0, 1), (5, 4), (17, 130), (300, 1), (299, 2), (42, 0)):
+        got = host(hip.container_decode(c, first, count)).view(dt)
+        assert np.array_equal(got, a[first * 256:(first + count) * 256]), (first, count)
+    # host buffers on both sides: the same bytes
+    ch = hip.container_encode_host(a)
+    assert np.array_equal(ch, raw)
+    assert np.array_equal(hip.container_decode_host(ch), a)
+    assert np.array_equal(hip.container_decode_host(ch, 100, 3), a[25600:26368])
+    # damaged or truncated containers are refused
+    bad = ch.copy()
+    bad[3] ^= 1
+    with pytest.raises(hip.OrochError):
+        hip.container_decode_host(bad)
+    with pytest.raises(hip.OrochError):
+        hip.container_decode_host(ch[:-16])
+    with pytest.raises(hip.OrochError):
+        hip.container_decode_host(ch, 301, 1)
+    # an empty array still makes a valid container
+    e = hip.container_encode_host(np.zeros(0, dt))
+    assert e.size == 80 and hip.container_decode_host(e).size == 0
