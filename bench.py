@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl is RCCL)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,6 +185,8 @@ def main():
     import oroch_amd
     from oroch_amd import sharding
 
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     rc = oroch_amd.lib.oroch_hip_init(local_rank)
@@ -189,7 +194,10 @@ def main():
         raise SystemExit("oroch_hip_init failed: %s" % oroch_amd.lib.oroch_hip_strerror(rc).decode())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     n = 1 << args.log2n
     seed = 3
