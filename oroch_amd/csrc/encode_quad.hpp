@@ -290,8 +290,12 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 	return fast;
 }
 
+// The kernel is latency-bound (dependent LDS round trips per quad), so it is
+// shaped for occupancy: registers capped for six wavefronts per SIMD, and the
+// one-block path's image shares LDS with the slots (the two are never live
+// together).
 template <typename E>
-__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode_quad(const typename E::S *__restrict__ src,
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_encode_quad(const typename E::S *__restrict__ src,
 								      size_t n, size_t nblocks,
 								      const oroch_block_desc *__restrict__ desc,
 								      const uint64_t *__restrict__ offsets,
@@ -301,10 +305,11 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode_quad(const typena
 	__shared__ __attribute__((aligned(16))) C slotss[WAVES_PER_WG][QUAD * SLOT_STRIDE];
 	__shared__ __attribute__((aligned(16))) uint8_t tailss[WAVES_PER_WG][QUAD * TAIL_BYTES];
 	__shared__ __attribute__((aligned(16))) uint8_t headss[WAVES_PER_WG][QUAD * 16];
-	__shared__ __attribute__((aligned(16))) uint32_t images[WAVES_PER_WG][image_bytes<E>() / 4];
+	static_assert(sizeof(C) * QUAD * SLOT_STRIDE >= size_t(image_bytes<E>()), "image must fit the slots");
 	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
 	load_width_table(wt);
+	uint32_t *image = reinterpret_cast<uint32_t *>(slotss[wave]);
 	const size_t nquads = (nblocks + QUAD - 1) / QUAD;
 	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
 	for (size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave; q < nquads; q += stride) {
@@ -332,9 +337,9 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode_quad(const typena
 				get_desc(&desc[blk], sel);
 				const uint64_t off = uniform(offsets[blk]);
 				const uint32_t len = nv == BLOCK
-							     ? encode_block<E, true>(v, nv, lane, sel, wt, images[wave])
-							     : encode_block<E, false>(v, nv, lane, sel, wt, images[wave]);
-				flush_image(images[wave], len, dst + off, lane);
+							     ? encode_block<E, true>(v, nv, lane, sel, wt, image)
+							     : encode_block<E, false>(v, nv, lane, sel, wt, image);
+				flush_image(image, len, dst + off, lane);
 				wave_sync();
 			}
 		}
