@@ -161,7 +161,7 @@ __device__ __forceinline__ void class_word(const quad_class &c, uint32_t p, uint
 // Lane p, p + 64, ... unpacks packed word p of the class.
 template <typename E, int NB>
 __device__ __forceinline__ void unpack_quad_words(const quad_class &c, const uint8_t *qb, uint32_t data_at,
-						  int lane, typename E::C *slots)
+						  int lane, typename E::C *slots, uint32_t first)
 {
 	using C = typename E::C;
 	constexpr uint32_t NBLK = (BLOCK + 128 / NB - 1) / (128 / NB); // packed words per block
@@ -180,23 +180,24 @@ __device__ __forceinline__ void unpack_quad_words(const quad_class &c, const uin
 			const uint2 *q = reinterpret_cast<const uint2 *>(qb + at) + j * 2;
 			const uint2 x = q[0], y = q[1];
 			const uint32_t w[4] = {x.x, x.y, y.x, y.y};
-			unpack_fields<C, NB>(w, slots + gp * SLOT_STRIDE, int(j));
+			unpack_fields<C, NB>(w, slots + (gp - first) * SLOT_STRIDE, int(j));
 		}
 	}
 }
 
 template <typename E, int LO, int HI>
 __device__ __forceinline__ void unpack_quad_dispatch(uint32_t nb, const quad_class &c, const uint8_t *qb,
-						     uint32_t data_at, int lane, typename E::C *slots)
+						     uint32_t data_at, int lane, typename E::C *slots,
+						     uint32_t first)
 {
 	if constexpr (LO == HI) {
-		unpack_quad_words<E, LO>(c, qb, data_at, lane, slots);
+		unpack_quad_words<E, LO>(c, qb, data_at, lane, slots, first);
 	} else {
 		constexpr int MID = (LO + HI) / 2;
 		if (nb <= uint32_t(MID))
-			unpack_quad_dispatch<E, LO, MID>(nb, c, qb, data_at, lane, slots);
+			unpack_quad_dispatch<E, LO, MID>(nb, c, qb, data_at, lane, slots, first);
 		else
-			unpack_quad_dispatch<E, MID + 1, HI>(nb, c, qb, data_at, lane, slots);
+			unpack_quad_dispatch<E, MID + 1, HI>(nb, c, qb, data_at, lane, slots, first);
 	}
 }
 
@@ -243,9 +244,9 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 	const uint32_t ilen_pck = 16u * __umulhi(m.nout + iw.x - 1u, iw.y); // bitpck.h:61-71
 	const uint32_t scan_rel = list_at + (m.inb ? ilen_pck : 0u);        // where varints start
 	if (is_pfr) {
-		ok = ok && m.nout >= 1 && m.nout <= uint32_t(BLOCK) && m.inb <= 32u && m.vnb <= uint32_t(E::W);
-		if (!m.inb || !m.vnb)
-			ok = ok && m.nout <= QUAD_MAX_EXC;
+		// one exception per lane of the group; a block with more goes the
+		// one-block way, where the whole wavefront shares the lists
+		ok = ok && m.nout >= 1 && m.nout <= QUAD_MAX_EXC && m.inb <= 32u && m.vnb <= uint32_t(E::W);
 		if (!m.vnb)
 			ok = ok && scan_rel <= len && len - scan_rel <= uint32_t(LIST_BYTES);
 		else
@@ -254,15 +255,13 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 	const uint32_t fast = group_mask(__ballot(ok));
 	if (fast == 0)
 		return 0;
-	// blocks of one width are unpacked together
-	for (uint32_t left = fast; left;) {
-		const uint32_t nb_u = read_lane(nb, int(__builtin_ctz(left)) * GROUP);
-		const uint32_t cls = group_mask(__ballot(ok && nb == nb_u));
-		unpack_quad_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, make_class(cls), qb, r0 + m.doff, lane, slots);
-		left &= ~cls;
-	}
 
-	const bool has_exc = ok && m.enc == OROCH_BITPFR;
+	// The exceptions of all four blocks first: position and shifted high part
+	// of exception `sub` of the group's block, to be OR-ed into the value slots.
+	const bool has_exc = ok && is_pfr;
+	bool hit = false;
+	uint32_t pos = 0;
+	C patch = 0;
 	if (__ballot(has_exc) != 0) {
 		const uint32_t lb = r0 + list_at;      // index list; a multiple of 8
 		const uint32_t sb = r0 + scan_rel;     // first varint, if any list has them
@@ -285,68 +284,86 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 		}
 		// where the value list starts when the index list is varints: after
 		// varint number nout - 1
-		const uint32_t vb = m.inb ? sb : sb + (has_exc && !m.inb ? my_ends[m.nout <= QUAD_MAX_EXC ? m.nout : 0u] : 0u);
+		const uint32_t vb = m.inb ? sb : sb + (has_exc ? my_ends[m.nout] : 0u);
 		const uint32_t voff = m.inb ? 0u : m.nout; // number of the first value varint
-		C *mine = slots + g * SLOT_STRIDE;
-		const uint32_t rounds = uniform(wave_max(has_exc ? (m.nout + GROUP - 1u) / GROUP : 0u));
-		uint32_t carry = 0;
-		for (uint32_t r = 0; r < rounds; r++) {
-			const uint32_t e = uint32_t(sub) + r * GROUP;
-			const bool active = has_exc && e < m.nout;
-			uint32_t gap = 0, hi = 0;
-			if (__ballot(active && m.inb) != 0) {
-				const uint32_t bk = __umulhi(e, iw.y);
-				gap = lds_get_bits32(qbuf, lb * 8u + bk * 128u + (e - bk * iw.x) * m.inb, m.inb ? m.inb : 1u);
-			}
-			if (__ballot(active && !m.inb) != 0) {
-				const uint32_t is = active && e && !m.inb ? my_ends[e] : 0u;
-				const uint32_t x = varint_at(qbuf, sb + is);
-				gap = m.inb ? gap : x;
-			}
-			if (__ballot(active && m.vnb) != 0) {
-				const uint32_t bk = __umulhi(e, vw.y);
-				hi = lds_get_bits32(qbuf, vb * 8u + bk * 128u + (e - bk * vw.x) * m.vnb, m.vnb ? m.vnb : 1u);
-			}
-			if (__ballot(active && !m.vnb) != 0) {
-				const uint32_t vs = active && !m.vnb && voff + e ? my_ends[voff + e] : 0u;
-				const uint32_t x = varint_at(qbuf, sb + vs);
-				hi = m.vnb ? hi : x;
-			}
-			// positions: running sum of gap + 1 (offset.h:62-67)
-			const uint32_t incl = row_scan_sum(active ? gap + 1u : 0u) + carry;
-			carry = lane_gather(incl, g * GROUP + GROUP - 1);
-			const uint32_t pos = incl - 1u;
-			const bool hit = active && pos < uint32_t(BLOCK);
-			// lanes with nothing to patch OR zero into a spare slot
-			atomicOr(&mine[hit ? pos : uint32_t(SLOT_STRIDE - 1)], hit ? C(hi << (nb & 31u)) & E::MASK : C(0));
+		const uint32_t e = uint32_t(sub);
+		const bool active = has_exc && e < m.nout;
+		uint32_t gap = 0, hi = 0;
+		if (__ballot(active && m.inb) != 0) {
+			const uint32_t bk = __umulhi(e, iw.y);
+			gap = lds_get_bits32(qbuf, lb * 8u + bk * 128u + (e - bk * iw.x) * m.inb, m.inb ? m.inb : 1u);
 		}
+		if (__ballot(active && !m.inb) != 0) {
+			const uint32_t is = active && e && !m.inb ? my_ends[e] : 0u;
+			const uint32_t x = varint_at(qbuf, sb + is);
+			gap = m.inb ? gap : x;
+		}
+		if (__ballot(active && m.vnb) != 0) {
+			const uint32_t bk = __umulhi(e, vw.y);
+			hi = lds_get_bits32(qbuf, vb * 8u + bk * 128u + (e - bk * vw.x) * m.vnb, m.vnb ? m.vnb : 1u);
+		}
+		if (__ballot(active && !m.vnb) != 0) {
+			const uint32_t vs = active && !m.vnb && voff + e ? my_ends[voff + e] : 0u;
+			const uint32_t x = varint_at(qbuf, sb + vs);
+			hi = m.vnb ? hi : x;
+		}
+		// positions: running sum of gap + 1 (offset.h:62-67)
+		pos = row_scan_sum(active ? gap + 1u : 0u) - 1u;
+		hit = active && pos < uint32_t(BLOCK);
+		patch = C(hi << (nb & 31u)) & E::MASK;
 	}
-	wave_sync();
 
-	// every lane picks up four values of each block; origin and encoding of
-	// block s come from the first lane of its group
+	// Two blocks at a time through the value slots (half the LDS of four, which
+	// buys a wavefront more per SIMD): unpack, patch, hand out.
 #pragma unroll
-	for (int s = 0; s < QUAD; s++) {
-		if (!((fast >> s) & 1u))
+	for (int half = 0; half < 2; half++) {
+		const uint32_t mine = fast & (3u << (2 * half));
+		if (mine == 0)
 			continue;
-		const uint32_t origin = read_lane(m.origin, s * GROUP);
-		const uint32_t enc = read_lane(m.enc, s * GROUP);
-		const uint4 q = *reinterpret_cast<const uint4 *>(&slots[s * SLOT_STRIDE + lane * VPL]);
-		C v[VPL] = {q.x, q.y, q.z, q.w};
+		const bool in_half = ok && (g >> 1) == half;
+		// blocks of one width are unpacked together
+		for (uint32_t left = mine; left;) {
+			const uint32_t nb_u = read_lane(nb, int(__builtin_ctz(left)) * GROUP);
+			const uint32_t cls = group_mask(__ballot(in_half && nb == nb_u));
+			unpack_quad_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, make_class(cls), qb, r0 + m.doff, lane, slots,
+								     uint32_t(2 * half));
+			left &= ~cls;
+		}
+		wave_sync();
+		// lanes with nothing to patch here OR zero into a spare slot
+		const bool now = hit && in_half;
+		atomicOr(&slots[now ? uint32_t(g & 1) * SLOT_STRIDE + pos : uint32_t(2 * SLOT_STRIDE - 1)],
+			 now ? patch : C(0));
+		wave_sync();
+		// every lane picks up four values of each block; origin and encoding
+		// of block s come from the first lane of its group
 #pragma unroll
-		for (int i = 0; i < VPL; i++)
-			v[i] = enc == OROCH_BITPCK ? unzz<E>(v[i] & E::MASK) : C((v[i] + origin) & E::MASK);
-		store_block<E>(dst, base + size_t(s) * BLOCK, BLOCK, lane, v);
+		for (int s = 2 * half; s < 2 * half + 2; s++) {
+			if (!((fast >> s) & 1u))
+				continue;
+			const uint32_t origin = read_lane(m.origin, s * GROUP);
+			const uint32_t enc = read_lane(m.enc, s * GROUP);
+			const uint4 q = *reinterpret_cast<const uint4 *>(&slots[(s & 1) * SLOT_STRIDE + lane * VPL]);
+			C v[VPL] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+			for (int i = 0; i < VPL; i++)
+				v[i] = enc == OROCH_BITPCK ? unzz<E>(v[i] & E::MASK) : C((v[i] + origin) & E::MASK);
+			store_block<E>(dst, base + size_t(s) * BLOCK, BLOCK, lane, v);
+		}
+		wave_sync();
 	}
 	return fast;
 }
 
 
 // Persistent wavefronts over quads of blocks; offsets are fetched two quads
-// ahead and the quad's bytes one quad ahead (the first QPRE KiB of them, in
-// registers), so the dependent latencies overlap with decoding.
+// ahead and the quad's bytes one quad ahead (the first 3 KiB of them, into
+// registers that are free again once the current quad is staged in LDS), so
+// the dependent latencies overlap with decoding.  The kernel is latency-bound
+// (a chain of LDS round trips per quad): registers and LDS are kept to what
+// five wavefronts per SIMD allow.
 template <typename E>
-__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_decode_quad(const uint8_t *__restrict__ src,
 								      const uint64_t *__restrict__ offsets,
 								      size_t n, size_t nblocks,
 								      typename E::S *__restrict__ dst)
@@ -357,7 +374,10 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 	constexpr int NCH = int((QBYTES + 1023) / 1024);
 	constexpr int NPRE = NCH < 3 ? NCH : 3;
 	__shared__ __attribute__((aligned(16))) uint32_t qbufs[WAVES_PER_WG][QBYTES / 4 + 24];
-	__shared__ __attribute__((aligned(16))) C slotss[WAVES_PER_WG][QUAD * SLOT_STRIDE];
+	// value slots of two blocks; the one-block path needs a little more
+	constexpr int SLOTS = SLOT_STRIDE + 2 * BLOCK;
+	static_assert(SLOTS >= 2 * SLOT_STRIDE, "two blocks of slots");
+	__shared__ __attribute__((aligned(16))) C slotss[WAVES_PER_WG][SLOTS];
 	__shared__ __attribute__((aligned(16))) uint8_t endss[WAVES_PER_WG][QUAD * ENDS];
 	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
@@ -396,26 +416,26 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 	size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave;
 	uint64_t o0, o1, o2, start0, start1;
 	uint32_t rel0, rel1, total0, total1;
-	uint4 im0[NPRE], im1[NPRE];
+	uint4 im[NPRE];
 	extent(q, o0);
 	extent(q + stride, o1);
 	resolve(o0, start0, rel0, total0);
-	fetch(start0, total0, im0);
+	fetch(start0, total0, im);
 	for (; q < nquads; q += stride) {
-		extent(q + 2 * stride, o2);
-		resolve(o1, start1, rel1, total1);
-		fetch(start1, total1, im1);
-
 #pragma unroll
 		for (int c = 0; c < NPRE; c++) {
 			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
 			if (o < total0)
-				*reinterpret_cast<uint4 *>(qb + o) = im0[c];
+				*reinterpret_cast<uint4 *>(qb + o) = im[c];
 		}
 		// a quad longer than what was fetched ahead: the rest, now
 		for (uint32_t o = uint32_t(NPRE) * 1024u + uint32_t(lane) * 16u; o < total0; o += 1024u)
 			*reinterpret_cast<uint4 *>(qb + o) = *reinterpret_cast<const uint4 *>(src + start0 + o);
 		wave_sync();
+		// the next quad's bytes and the offsets of the one after it, on their way
+		extent(q + 2 * stride, o2);
+		resolve(o1, start1, rel1, total1);
+		fetch(start1, total1, im);
 
 		const size_t blk0 = q * QUAD;
 		const size_t base = blk0 * BLOCK;
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 				C v[VPL];
 				uint32_t *img = qbuf + (at >> 2);
 				C *val = slots, *hv = slots + SLOT_STRIDE;
-				uint32_t *gp = reinterpret_cast<uint32_t *>(slots + 2 * SLOT_STRIDE);
+				uint32_t *gp = reinterpret_cast<uint32_t *>(slots + SLOT_STRIDE + BLOCK);
 				if (nv == BLOCK)
 					decode_block<E, true>(img, len, nv, lane, val, hv, gp, wt, v);
 				else
@@ -448,9 +468,6 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode_quad(const uint8_
 		start0 = start1;
 		rel0 = rel1;
 		total0 = total1;
-#pragma unroll
-		for (int c = 0; c < NPRE; c++)
-			im0[c] = im1[c];
 	}
 }
 
