@@ -186,8 +186,10 @@ int oroch_group_encode(int dtype, const void *src, size_t n, void *dst, size_t d
 /*
  * integer_group<T>::decode, integer_group.h:62-76, for every block of a
  * stream produced by oroch_group_encode (or by the reference's integer_group
- * laid out the same way).  src must be readable up to the stream length
- * rounded up to 16 bytes.
+ * laid out the same way).  src must be readable up to the stream length,
+ * offsets[ceil(n / block)], rounded up to 16 bytes.  The other offsets and the
+ * stream bytes are not trusted: damage there gives wrong values, not reads
+ * outside the stream or writes outside dst[0..n).
  */
 int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n, void *dst,
 		       void *stream);

@@ -398,9 +398,16 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 			o = __builtin_nontemporal_load(offsets + i);
 		}
 	};
+	// Offsets come from the caller's table and may be anything: the quad is
+	// confined to [0, offsets[nblocks]), the length of the stream, so a damaged
+	// table yields wrong values but no read outside the stream.
+	const uint64_t limit = uniform(offsets[nblocks]);
 	auto resolve = [&](uint64_t o, uint64_t &start, uint32_t &rel, uint32_t &total) {
-		start = read_lane(o, 0);
-		rel = clamp_u64(o - start, QBYTES);
+		start = min_u64(read_lane(o, 0), limit) & ~uint64_t(15);
+		const uint64_t room = limit - start;
+		uint64_t d = o >= start ? o - start : 0; // per lane
+		d = d < room ? d : room;
+		rel = clamp_u64(d, QBYTES) & ~15u; // images start at multiples of 16
 		total = read_lane(rel, QUAD);
 	};
 	auto fetch = [&](uint64_t start, uint32_t total, uint4 (&im)[NPRE]) {

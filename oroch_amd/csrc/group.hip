@@ -35,6 +35,13 @@ __device__ __forceinline__ uint32_t clamp_u64(uint64_t x, uint32_t cap)
 	const uint32_t lo = uint32_t(x), hi = uint32_t(x >> 32);
 	return hi ? cap : (lo < cap ? lo : cap);
 }
+// min(a, b) of two wave-uniform 64-bit values, on 32-bit compares for the same reason.
+__device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b)
+{
+	const uint32_t ah = uint32_t(a >> 32), bh = uint32_t(b >> 32);
+	const bool less = ah < bh || (ah == bh && uint32_t(a) < uint32_t(b));
+	return less ? a : b;
+}
 // Values in block number blk of an n-value array.
 __device__ __forceinline__ int block_count(size_t n, size_t blk)
 {
@@ -1389,11 +1396,18 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__
 			end = x;
 		}
 	};
+	// Offsets come from the caller's table and may be anything: every block is
+	// confined to [0, offsets[nblocks]), the length of the stream, so a damaged
+	// table yields wrong values but no read outside the stream.
+	const uint64_t limit = uniform(offsets[nblocks]);
 	auto resolve = [&](uint64_t &off, uint64_t end, uint32_t &len) {
 		// lane 0 holds offsets[blk], lane 1 offsets[blk + 1]
-		const uint64_t o = read_lane(off, 0), e = read_lane(end, 1);
+		const uint64_t o = min_u64(read_lane(off, 0), limit) & ~uint64_t(15);
+		const uint64_t e = min_u64(read_lane(end, 1), limit);
 		off = o;
-		len = clamp_u64(e - o, MAXLEN);
+		const uint32_t eh = uint32_t(e >> 32), oh = uint32_t(o >> 32);
+		const bool forward = eh > oh || (eh == oh && uint32_t(e) >= uint32_t(o));
+		len = forward ? clamp_u64(e - o, MAXLEN) : 0u;
 	};
 	auto fetch = [&](uint64_t off, uint32_t len, uint4 (&im)[NCH]) {
 #pragma unroll

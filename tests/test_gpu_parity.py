@@ -385,3 +385,38 @@ def test_serialised_container(hip, oracle, dt):
     # an empty array still makes a valid container
     e = hip.container_encode_host(np.zeros(0, dt))
     assert e.size == 80 and hip.container_decode_host(e).size == 0
+
+
+@pytest.mark.parametrize("dt", [np.int32, np.int64])
+def test_damaged_streams_stay_inside_the_stream(hip, dt):
+    """Decoding is for files and network buffers: a damaged offsets table or
+    damaged block bytes may give wrong values, never a read outside the stream
+    (which would show up here as a GPU fault)."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    a = np.concatenate([dg.fuzz_block(rng, dt, 256) for _ in range(64)])
+    stream, offs = hip.group_encode(dev(a))
+    n = a.size
+    good = host(hip.group_decode(stream, offs, n, dt))
+    assert np.array_equal(good.view(dt), a)
+    total = int(offs[-1])
+    # offsets: out of order, beyond the end, misaligned, enormous (the last entry,
+    # the stream length the caller vouches for, stays)
+    o = host(offs).astype(np.uint64)
+    bad = o.copy()
+    bad[3], bad[4] = bad[4], bad[3]
+    bad[10] = np.uint64(total + 4096)
+    bad[17] += np.uint64(5)
+    bad[30] = np.uint64(2 ** 63 + 12345)
+    bad[40] = np.uint64(0)
+    got = host(hip.group_decode(stream, torch.from_numpy(bad.astype(np.int64)).cuda(), n, dt)).view(dt)
+    ok_blocks = [b for b in range(64) if all(bad[b + d] == o[b + d] for d in (0, 1))]
+    for b in ok_blocks[:8] + ok_blocks[-8:]:
+        assert np.array_equal(got[b * 256:(b + 1) * 256], a[b * 256:(b + 1) * 256]), b
+    # block bytes: random damage in a copy of the stream
+    s = host(stream).copy()
+    hits = rng.integers(0, s.size, size=400)
+    s[hits] ^= rng.integers(1, 256, size=400).astype(np.uint8)
+    hip.group_decode(torch.from_numpy(s).cuda(), offs, n, dt)
+    torch.cuda.synchronize()
