@@ -1,4 +1,4 @@
-"""Times the group kernels for a dtype/distribution: DT=int64 LOG2N=27 python3 scratch/time_any.py"""
+"""Times the group kernels for a dtype/distribution: DT=int64 LOG2N=27 python3 tools/time_any.py"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

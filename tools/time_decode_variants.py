@@ -1,4 +1,4 @@
-"""Encode with the default library, decode with the library OROCH_DEC names (for counters)."""
+"""Encodes with the default library, then times oroch_group_decode of every library given on the command line (experiment builds from tools/build_variants.sh)."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,8 +12,6 @@ if os.environ.get("KIND") == "uniform":
     x = devgen.uniform_bits(n, torch.int32, 3, int(os.environ.get("BODY", "13")), torch.device("cuda", 0))
 enc = oroch_amd.GroupEncoder(np.int32, n, x.device)
 enc.encode(x)
-d = oroch_amd.group_select(x[:4096])
-print("first descs", d[:4])
 back = torch.empty_like(x)
 torch.cuda.synchronize()
 for path in sys.argv[1:]:
@@ -25,8 +23,4 @@ for path in sys.argv[1:]:
         L.oroch_group_decode(4, enc.out.data_ptr(), enc.offsets.data_ptr(), n, back.data_ptr(), None)
     ev[1].record()
     torch.cuda.synchronize()
-    if hasattr(L, "oroch_debug_quad_count"):
-        c = (ctypes.c_ulonglong * 2)()
-        L.oroch_debug_quad_count(c)
-        print("fast quads", c[0], "slow quads", c[1])
     print(os.path.basename(path), "decode ms scaled to 2^30: %.3f" % (ev[0].elapsed_time(ev[1]) / 2 * (1 << 30) / n), "ok" if torch.equal(back, x) else "MISMATCH")
