@@ -29,41 +29,6 @@ __device__ __forceinline__ int row_scan_max(int x)
 	return x;
 }
 
-// Sixteen consecutive elements at p (16-byte aligned) as raw W-bit patterns.
-template <typename E>
-__device__ __forceinline__ void load16(const typename E::S *p, typename E::C (&v)[VPQ])
-{
-	const uint4 *q = reinterpret_cast<const uint4 *>(p);
-	if constexpr (E::BYTES == 4) {
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const uint4 a = q[k];
-			v[4 * k] = a.x, v[4 * k + 1] = a.y, v[4 * k + 2] = a.z, v[4 * k + 3] = a.w;
-		}
-	} else if constexpr (E::BYTES == 2) {
-#pragma unroll
-		for (int k = 0; k < 2; k++) {
-			const uint4 a = q[k];
-			const uint32_t d[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				v[8 * k + 2 * i] = d[i] & 0xffffu;
-				v[8 * k + 2 * i + 1] = d[i] >> 16;
-			}
-		}
-	} else {
-		const uint4 a = q[0];
-		const uint32_t d[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			v[4 * i] = d[i] & 0xffu;
-			v[4 * i + 1] = (d[i] >> 8) & 0xffu;
-			v[4 * i + 2] = (d[i] >> 16) & 0xffu;
-			v[4 * i + 3] = d[i] >> 24;
-		}
-	}
-}
-
 // Lane p, p + 64, ... packs word p of a class of blocks (see class_word) from
 // the slots and stores it at its place in the stream.
 template <typename E, int NB>

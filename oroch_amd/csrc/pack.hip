@@ -128,55 +128,61 @@ __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t 
 // consecutive values per thread.
 
 constexpr int XT_THREADS = 256;
-constexpr int XT_VPT = 4;
+constexpr int XT_VPT = 16;
 constexpr int XT_TILE = XT_THREADS * XT_VPT;
 constexpr uint64_t XT_NONE = ~uint64_t(0);
 
+// Bit s set when value base + s does not fit nbits after the origin is taken
+// off (bitpfr.h:75-85).  Sixteen consecutive values per thread, one to four
+// 16-byte loads.
 template <typename E>
 __device__ __forceinline__ uint32_t exc_flags(const typename E::S *src, size_t n, size_t base,
-					      typename E::C origin, uint32_t nbits,
-					      typename E::C (&hi)[XT_VPT])
+					      typename E::C origin, uint32_t nbits)
 {
 	using C = typename E::C;
+	C u[XT_VPT];
+	if (base + XT_VPT <= n) {
+		load16<E>(src + base, u);
+	} else {
+#pragma unroll
+		for (int s = 0; s < XT_VPT; s++)
+			u[s] = base + s < n ? C(src[base + s]) : origin;
+	}
 	uint32_t flags = 0;
 #pragma unroll
 	for (int s = 0; s < XT_VPT; s++) {
-		hi[s] = 0;
-		if (base + s < n) {
-			C u = (C(src[base + s]) - origin) & E::MASK;
-			hi[s] = u >> nbits;   // nbits < W for bitpfr (bitpfr.h:65)
-			if (hi[s])
-				flags |= 1u << s;
-		}
+		const C hi = C((u[s] - origin) & E::MASK) >> nbits; // nbits < W for bitpfr (bitpfr.h:65)
+		flags |= (hi ? 1u : 0u) << s;
 	}
 	return flags;
 }
 
-// Pass 1: per tile, the number of exceptions and the position of the last one.
+// Pass 1: per tile of 4096 values, the number of exceptions and the position
+// of the last one.
 template <typename E>
 __global__ __launch_bounds__(XT_THREADS) void k_exc_count(const typename E::S *src, size_t n,
 							    typename E::C origin, uint32_t nbits,
 							    uint32_t *counts, uint64_t *last)
 {
-	__shared__ uint64_t lds[XT_THREADS / WAVE];
-	__shared__ uint64_t lastpos[XT_THREADS / WAVE];
-	const size_t base = size_t(blockIdx.x) * XT_TILE + size_t(threadIdx.x) * XT_VPT;
-	typename E::C hi[XT_VPT];
-	const uint32_t flags = exc_flags<E>(src, n, base, origin, nbits, hi);
-	uint64_t all;
-	wg_scan_u64(uint64_t(__popc(flags)), lds, &all);
-	// highest position with an exception: position + 1, 0 = none
-	uint64_t lp = flags ? base + (31 - __clz(flags)) + 1 : 0;
-	lp = wave_max(lp);
-	if (lane_id() == 0)
-		lastpos[threadIdx.x / WAVE] = lp;
+	__shared__ uint32_t wave_cnt[XT_THREADS / WAVE], wave_last[XT_THREADS / WAVE];
+	const size_t tile_base = size_t(blockIdx.x) * XT_TILE;
+	const uint32_t flags = exc_flags<E>(src, n, tile_base + size_t(threadIdx.x) * XT_VPT, origin, nbits);
+	const uint32_t cnt = wave_sum(uint32_t(__popc(flags)));
+	// highest position in the tile with an exception, plus one; 0 = none
+	const uint32_t lp = wave_max(flags ? threadIdx.x * XT_VPT + (31u - uint32_t(__clz(flags))) + 1u : 0u);
+	if (lane_id() == 0) {
+		wave_cnt[threadIdx.x / WAVE] = cnt;
+		wave_last[threadIdx.x / WAVE] = lp;
+	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		uint64_t m = 0;
-		for (int w = 0; w < XT_THREADS / WAVE; w++)
-			m = lastpos[w] > m ? lastpos[w] : m;
-		counts[blockIdx.x] = uint32_t(all);
-		last[blockIdx.x] = m ? m - 1 : XT_NONE;
+		uint32_t total = 0, m = 0;
+		for (int w = 0; w < XT_THREADS / WAVE; w++) {
+			total += wave_cnt[w];
+			m = wave_last[w] > m ? wave_last[w] : m;
+		}
+		counts[blockIdx.x] = total;
+		last[blockIdx.x] = m ? tile_base + m - 1 : XT_NONE;
 	}
 }
 
@@ -188,80 +194,65 @@ __global__ __launch_bounds__(XT_THREADS) void k_exc_emit(const typename E::S *sr
 							   const uint64_t *rank_base, uint64_t *indices,
 							   uint64_t *values, size_t capacity)
 {
-	__shared__ uint64_t lds[XT_THREADS / WAVE];
-	__shared__ uint64_t prev_tile;
-	__shared__ uint64_t wave_last[XT_THREADS / WAVE];
+	using C = typename E::C;
+	__shared__ uint64_t before_tile;
+	__shared__ uint32_t wave_cnt[XT_THREADS / WAVE], wave_last[XT_THREADS / WAVE];
 	const size_t tile = blockIdx.x;
 	if (counts[tile] == 0)
 		return;
-	// the last exception before this tile: nearest earlier tile that has one
-	if (threadIdx.x == 0)
-		prev_tile = XT_NONE;
-	__syncthreads();
-	for (size_t hiT = tile; hiT > 0;) {
-		const size_t lo = hiT > XT_THREADS ? hiT - XT_THREADS : 0;
-		const size_t t = lo + threadIdx.x;
-		uint64_t cand = 0;
-		if (t < hiT && last[t] != XT_NONE)
-			cand = last[t] + 1;
-		// positions grow with the tile index, so the maximum is the nearest
-		cand = wave_max(cand);
-		if (lane_id() == 0)
-			wave_last[threadIdx.x / WAVE] = cand;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			uint64_t m = 0;
-			for (int w = 0; w < XT_THREADS / WAVE; w++)
-				m = wave_last[w] > m ? wave_last[w] : m;
-			if (m)
-				prev_tile = m - 1;
-		}
-		__syncthreads();
-		if (prev_tile != XT_NONE)
-			break;
-		hiT = lo;
-		__syncthreads();
-	}
-	const uint64_t before = prev_tile;
-
-	const size_t base = tile * XT_TILE + size_t(threadIdx.x) * XT_VPT;
-	typename E::C hi[XT_VPT];
-	const uint32_t flags = exc_flags<E>(src, n, base, origin, nbits, hi);
-	uint64_t all;
-	const uint32_t cnt = uint32_t(__popc(flags));
-	uint64_t rank = rank_base[tile] + wg_scan_u64(cnt, lds, &all) - cnt;
-
-	// last exception position in lower threads of this tile (position + 1, 0 = none)
 	const int lane = lane_id(), wave = threadIdx.x / WAVE;
-	uint64_t lp = flags ? base + (31 - __clz(flags)) + 1 : 0;
-	uint64_t incl = lp;
-#pragma unroll
-	for (int o = 1; o < WAVE; o <<= 1) {
-		uint64_t y = __shfl_up(incl, o, WAVE);
-		if (lane >= o)
-			incl = y > incl ? y : incl;
+	// The last exception before this tile: the nearest earlier tile that has
+	// one, looked for by the first wavefront, 64 tiles per step.
+	if (wave == 0) {
+		uint64_t found = XT_NONE;
+		for (size_t hi = tile; hi > 0 && found == XT_NONE;) {
+			const size_t lo = hi > WAVE ? hi - WAVE : 0;
+			const size_t t = lo + size_t(lane);
+			const uint64_t x = t < hi ? last[t] : XT_NONE;
+			const uint64_t have = __ballot(x != XT_NONE);
+			if (have)
+				found = read_lane(x, 63 - __builtin_clzll(have));
+			hi = lo;
+		}
+		if (lane == 0)
+			before_tile = found;
 	}
-	if (lane == WAVE - 1)
-		wave_last[wave] = incl;
+
+	const size_t tile_base = tile * XT_TILE;
+	const size_t base = tile_base + size_t(threadIdx.x) * XT_VPT;
+	uint32_t flags = exc_flags<E>(src, n, base, origin, nbits);
+	const uint32_t cnt = uint32_t(__popc(flags));
+	const uint32_t incl_cnt = wave_scan_sum(cnt, lane);
+	// last exception at or below this thread, as tile position + 1 (0 = none)
+	const int lp = flags ? int(threadIdx.x * XT_VPT + (31u - uint32_t(__clz(flags))) + 1u) : 0;
+	const int incl_last = wave_scan_max(lp, lane);
+	if (lane == WAVE - 1) {
+		wave_cnt[wave] = incl_cnt;
+		wave_last[wave] = uint32_t(incl_last);
+	}
 	__syncthreads();
-	uint64_t prevp = __shfl_up(incl, 1, WAVE);
+	uint32_t rank_in_tile = incl_cnt - cnt;
+	int prevp = __shfl_up(incl_last, 1, WAVE);
 	if (lane == 0)
 		prevp = 0;
-	for (int w = 0; w < wave; w++)
-		prevp = wave_last[w] > prevp ? wave_last[w] : prevp;
+	for (int w = 0; w < wave; w++) {
+		rank_in_tile += wave_cnt[w];
+		prevp = int(wave_last[w]) > prevp ? int(wave_last[w]) : prevp;
+	}
+	uint64_t rank = rank_base[tile] + rank_in_tile;
+	const uint64_t before = before_tile;
 	// next expected position (offset.h:55-60): previous + 1, or 0 at the start
-	uint64_t next = prevp ? prevp : (before == XT_NONE ? 0 : before + 1);
-#pragma unroll
-	for (int s = 0; s < XT_VPT; s++) {
-		if (flags & (1u << s)) {
-			const uint64_t pos = base + s;
-			if (rank < capacity) {
-				indices[rank] = pos - next;
-				values[rank] = uint64_t(hi[s]);
-			}
-			next = pos + 1;
-			rank++;
+	uint64_t next = prevp ? tile_base + uint64_t(prevp) : (before == XT_NONE ? 0 : before + 1);
+	while (flags) {
+		const uint64_t pos = base + uint64_t(__builtin_ctz(flags));
+		flags &= flags - 1u;
+		if (rank < capacity) {
+			const C u = C((C(src[pos]) - origin) & E::MASK);
+			indices[rank] = pos - next;
+			values[rank] = uint64_t(u >> nbits);
 		}
+		next = pos + 1;
+		rank++;
 	}
 }
 
