@@ -118,6 +118,15 @@ int oroch_bitfor_decode(int dtype, const void *src, size_t n, uint64_t origin, u
 			void *dst, void *stream);
 
 /*
+ * bitpck_codec<T,V>::fetch, bitpck.h:203-225, 258-266, and bitfor_codec<T>::fetch,
+ * bitfor.h:71-74, for a batch of positions: dst[i] = value number index[i] of
+ * the packed sequence of n values at src (8-byte aligned).  vcodec: 0 = zigzag
+ * (bitpck), 1 = origin (bitfor).  A position >= n reads as a packed zero.
+ */
+int oroch_bitpck_fetch(int dtype, int vcodec, const void *src, size_t n, uint64_t origin,
+		       unsigned nbits, const uint64_t *index, size_t m, void *dst, void *stream);
+
+/*
  * bitpfr_codec<T>::encode, bitpfr.h:95-99 with parameters::value_encode
  * (bitpfr.h:75-85): packs the low nbits of (v - origin) and appends, in
  * sequence order, one entry per value that does not fit: the gap-coded

@@ -17,6 +17,7 @@ from .capi import (  # noqa: F401
     bitpck_encode,
     bitpck_space,
     bitpfr_decode,
+    bitpck_fetch,
     bitpfr_encode,
     dtype_code,
     group_bound,

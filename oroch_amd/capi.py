@@ -63,6 +63,7 @@ def _load():
         "oroch_bitpfr_workspace": (sz, [sz]),
         "oroch_bitpfr_encode": (i, [i, vp, sz, u64, u32, vp, vp, vp, sz, vp, vp, sz, vp]),
         "oroch_bitpfr_decode": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp, vp, sz, vp]),
+        "oroch_bitpck_fetch": (i, [i, i, vp, sz, u64, u32, vp, sz, vp, vp]),
         "oroch_bitpfr_patch": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp, sz, vp]),
         "oroch_group_select": (i, [i, vp, sz, vp, vp]),
         "oroch_group_bound": (sz, [i, sz]),
@@ -203,6 +204,18 @@ def bitpfr_decode(b, n, origin, nbits, idx, val, dtype):
     _check(lib.oroch_bitpfr_decode(code, b.data_ptr(), n, _raw64(origin, code), nbits,
                                    idx.data_ptr(), val.data_ptr(), idx.numel(), out.data_ptr(),
                                    ws.data_ptr(), wsb, _stream()))
+    return out
+
+
+def bitpck_fetch(b, n, nbits, index, dtype, origin=None):
+    """Values number index[i] of a packed sequence (bitfor when an origin is given)."""
+    import torch
+
+    code = dtype_code(dtype)
+    out = torch.empty(index.numel(), dtype=_torch_dtype(code), device=b.device)
+    _check(lib.oroch_bitpck_fetch(code, 0 if origin is None else 1, b.data_ptr(), n,
+                                  0 if origin is None else _raw64(origin, code), nbits, index.data_ptr(),
+                                  index.numel(), out.data_ptr(), _stream()))
     return out
 
 

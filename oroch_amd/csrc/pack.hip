@@ -122,6 +122,35 @@ __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t 
 	}
 }
 
+// Random access, bitpck.h:203-225, 258-266 and bitfor.h:71-74: value number
+// index[i] of a packed sequence, straight from global memory (each value
+// touches one or two qwords of its 16-byte block).
+template <typename E, int VC>
+__global__ __launch_bounds__(PK_THREADS) void k_fetch(const uint64_t *src, size_t n,
+							const uint64_t *index, size_t m, pack_geom g,
+							typename E::C origin, typename E::S *dst)
+{
+	using C = typename E::C;
+	using S = typename E::S;
+	const C low = g.nbits >= uint32_t(E::W) ? E::MASK : C((C(1) << (g.nbits % E::W)) - 1);
+	for (size_t i = size_t(blockIdx.x) * PK_THREADS + threadIdx.x; i < m; i += size_t(gridDim.x) * PK_THREADS) {
+		const uint64_t at = index[i];
+		C u = 0;
+		if (at < n) {
+			const uint64_t blk = at / g.cap;
+			const uint32_t bit = uint32_t(at - blk * g.cap) * g.nbits; // 0..127
+			const uint64_t *q = src + blk * 2;
+			const uint64_t lo = q[bit >> 6];
+			const uint32_t sh = bit & 63u;
+			uint64_t x = lo >> sh;
+			if (sh + g.nbits > 64u)
+				x |= q[1] << (64u - sh);
+			u = C(x) & low;
+		}
+		dst[i] = S(value_decode<E, VC>(u, origin));
+	}
+}
+
 // ---- bitpfr exception lists ---------------------------------------------------------
 //
 // A tile is 1024 consecutive values handled by one 256-thread workgroup, four
@@ -433,6 +462,40 @@ extern "C" int oroch_bitfor_decode(int dtype, const void *src, size_t n, uint64_
 				   unsigned nbits, void *dst, void *stream)
 {
 	return do_unpack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
+}
+
+extern "C" int oroch_bitpck_fetch(int dtype, int vcodec, const void *src, size_t n, uint64_t origin,
+				  unsigned nbits, const uint64_t *index, size_t m, void *dst, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	const unsigned W = 8u << (dtype >> 1);
+	if (nbits < 1 || nbits > W)
+		return OROCH_E_NBITS;
+	if (vcodec != VC_ZIGZAG && vcodec != VC_ORIGIN)
+		return OROCH_E_ARGUMENT;
+	if (m == 0)
+		return 0;
+	if (!src || !index || !dst || (reinterpret_cast<uintptr_t>(src) & 7u))
+		return OROCH_E_ARGUMENT;
+	const pack_geom g = make_geom(nbits);
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const size_t wgs = (m + PK_THREADS - 1) / PK_THREADS;
+	const unsigned grid = unsigned(wgs < 65536 ? wgs : 65536);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		profile_scope ps(OROCH_K_UNPACK, st);
+		const typename E::C org = typename E::C(origin & uint64_t(E::MASK));
+		if (vcodec == VC_ZIGZAG)
+			hipLaunchKernelGGL((k_fetch<E, VC_ZIGZAG>), dim3(grid), dim3(PK_THREADS), 0, st,
+					   static_cast<const uint64_t *>(src), n, index, m, g, org,
+					   static_cast<typename E::S *>(dst));
+		else
+			hipLaunchKernelGGL((k_fetch<E, VC_ORIGIN>), dim3(grid), dim3(PK_THREADS), 0, st,
+					   static_cast<const uint64_t *>(src), n, index, m, g, org,
+					   static_cast<typename E::S *>(dst));
+		return int(hipGetLastError());
+	});
 }
 
 extern "C" size_t oroch_bitpfr_workspace(size_t n)

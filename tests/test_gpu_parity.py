@@ -420,3 +420,30 @@ def test_damaged_streams_stay_inside_the_stream(hip, dt):
     s[hits] ^= rng.integers(1, 256, size=400).astype(np.uint8)
     hip.group_decode(torch.from_numpy(s).cuda(), offs, n, dt)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dt", [np.uint8, np.int16, np.uint32, np.int64])
+def test_batched_fetch(hip, oracle, dt):
+    """Random access into packed sequences (bitpck.h:258-266, bitfor.h:71-74)."""
+    import torch
+
+    dt = np.dtype(dt)
+    W = dt.itemsize * 8
+    rng = np.random.default_rng(31)
+    n = 50021
+    for nbits in sorted({1, 3, 7, W // 2 + 1, W - 1, W}):
+        a = dg.uniform_bits(n, dt, nbits, min(nbits, W - 1) if dt.kind == "i" else nbits)
+        if dt.kind == "i":
+            a = (a >> 1) * np.where(a & 1, -1, 1).astype(dt)   # zigzag image below 2^nbits
+        idx = rng.integers(0, n, size=20000).astype(np.int64)
+        idx[:3] = (0, n - 1, n // 2)
+        b = dev(oracle.bitpck_encode(a, nbits))
+        got = host(hip.bitpck_fetch(b, n, nbits, dev(idx), dt)).view(dt)
+        assert np.array_equal(got, a[idx]), nbits
+        if nbits < W:
+            origin = int(rng.integers(-1000, 1000)) if dt.kind == "i" else int(rng.integers(0, 100))
+            f = (dg.uniform_bits(n, np.dtype("u%d" % dt.itemsize), nbits + 1, nbits).astype(np.int64) + origin)
+            f = f.astype(dt)
+            b = dev(oracle.bitfor_encode(f, origin, nbits))
+            got = host(hip.bitpck_fetch(b, n, nbits, dev(idx), dt, origin=origin)).view(dt)
+            assert np.array_equal(got, f[idx]), nbits
