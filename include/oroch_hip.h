@@ -156,6 +156,24 @@ int oroch_bitpfr_patch(int dtype, void *dst, size_t n, uint64_t origin, unsigned
 		       const uint64_t *indices, const uint64_t *values, size_t nexc,
 		       void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * varint_codec<T>::space / encode / decode over a whole sequence, varint.h
+ * :124-147, default value codec (zigzag for signed T).  workspace:
+ * oroch_varint_workspace(units) bytes with units = n for space / encode and
+ * units = nbytes for decode.  encode needs room for the worst case,
+ * n * ceil(bits(T) / 7) bytes; space and (when total_host is not NULL) encode
+ * wait for the stream and return the byte count.  decode reads n values from the
+ * nbytes at src (16-byte aligned); bytes that do not form n complete values
+ * leave the remaining outputs untouched.
+ */
+size_t oroch_varint_workspace(size_t units);
+int oroch_varint_space(int dtype, const void *src, size_t n, void *workspace, size_t workspace_bytes,
+		       uint64_t *space_host, void *stream);
+int oroch_varint_encode(int dtype, const void *src, size_t n, void *dst, size_t dst_capacity,
+			void *workspace, size_t workspace_bytes, uint64_t *total_host, void *stream);
+int oroch_varint_decode(int dtype, const void *src, size_t nbytes, size_t n, void *dst,
+			void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- per-block statistics, selection, batch encode / decode --------------- */
 
 /*

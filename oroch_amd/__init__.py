@@ -29,6 +29,9 @@ from .capi import (  # noqa: F401
     container_encode_host,
     container_header,
     group_encode,
+    varint_decode,
+    varint_encode,
+    varint_space,
     group_encode_host,
     group_select,
     group_stats,

@@ -64,6 +64,10 @@ def _load():
         "oroch_bitpfr_encode": (i, [i, vp, sz, u64, u32, vp, vp, vp, sz, vp, vp, sz, vp]),
         "oroch_bitpfr_decode": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp, vp, sz, vp]),
         "oroch_bitpck_fetch": (i, [i, i, vp, sz, u64, u32, vp, sz, vp, vp]),
+        "oroch_varint_workspace": (sz, [sz]),
+        "oroch_varint_space": (i, [i, vp, sz, vp, sz, vp, vp]),
+        "oroch_varint_encode": (i, [i, vp, sz, vp, sz, vp, sz, vp, vp]),
+        "oroch_varint_decode": (i, [i, vp, sz, sz, vp, vp, sz, vp]),
         "oroch_bitpfr_patch": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp, sz, vp]),
         "oroch_group_select": (i, [i, vp, sz, vp, vp]),
         "oroch_group_bound": (sz, [i, sz]),
@@ -216,6 +220,45 @@ def bitpck_fetch(b, n, nbits, index, dtype, origin=None):
     _check(lib.oroch_bitpck_fetch(code, 0 if origin is None else 1, b.data_ptr(), n,
                                   0 if origin is None else _raw64(origin, code), nbits, index.data_ptr(),
                                   index.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def varint_space(x):
+    """Bytes of the varint coding of a 1-D CUDA tensor (varint.h:124-131)."""
+    import torch
+
+    code = dtype_code(x.dtype)
+    wsb = lib.oroch_varint_workspace(x.numel())
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+    out = C.c_uint64(0)
+    _check(lib.oroch_varint_space(code, x.data_ptr(), x.numel(), ws.data_ptr(), wsb, C.byref(out), _stream()))
+    return out.value
+
+
+def varint_encode(x):
+    import torch
+
+    code = dtype_code(x.dtype)
+    n = x.numel()
+    worst = n * ((x.element_size() * 8 + 6) // 7)
+    out = torch.empty(max(worst, 16), dtype=torch.uint8, device=x.device)
+    wsb = lib.oroch_varint_workspace(n)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+    total = C.c_uint64(0)
+    _check(lib.oroch_varint_encode(code, x.data_ptr(), n, out.data_ptr(), worst, ws.data_ptr(), wsb,
+                                   C.byref(total), _stream()))
+    return out[:total.value]
+
+
+def varint_decode(b, n, dtype):
+    import torch
+
+    code = dtype_code(dtype)
+    out = torch.zeros(n, dtype=_torch_dtype(code), device=b.device)
+    wsb = lib.oroch_varint_workspace(b.numel())
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=b.device)
+    _check(lib.oroch_varint_decode(code, b.data_ptr(), b.numel(), n, out.data_ptr(), ws.data_ptr(), wsb,
+                                   _stream()))
     return out
 
 

@@ -36,3 +36,8 @@ x = devgen.outlier_mix(n, torch.int64, 3, dev).to(torch.int32).view(torch.uint32
 b, idx, val, k = oroch_amd.bitpfr_encode(x, 0, 10, capacity=n // 64)
 run("bitpfr uint32 10-bit + 1%% encode 2^28 (%d exceptions)" % k, lambda: oroch_amd.bitpfr_encode(x, 0, 10, capacity=n // 64), 4 * n, b.numel() + 16 * k)
 run("bitpfr uint32 10-bit + 1% decode 2^28", lambda: oroch_amd.bitpfr_decode(b, n, 0, 10, idx, val, np.uint32), 4 * n, b.numel() + 16 * k)
+n = 1 << 28
+x = devgen.outlier_mix(n, torch.int64, 3, dev, shift=-200).to(torch.int32)
+v = oroch_amd.varint_encode(x)
+run("varint int32 (bench distribution) encode 2^28", lambda: oroch_amd.varint_encode(x), 4 * n, v.numel())
+run("varint int32 (bench distribution) decode 2^28", lambda: oroch_amd.varint_decode(v, n, np.int32), 4 * n, v.numel())
