@@ -46,6 +46,7 @@ enum {
 	OROCH_E_CAPACITY = -4,  /* destination / workspace too small */
 	OROCH_E_ARGUMENT = -5,  /* null pointer or inconsistent sizes */
 	OROCH_E_NOGPU = -6,     /* no usable HIP device */
+	OROCH_E_RANGE = -7,     /* position outside the array */
 };
 
 /* Values per block of the batch (group) entry points; integer_array.h:44. */
@@ -314,6 +315,86 @@ int oroch_container_encode_host(int dtype, const void *src_host, size_t n, void 
 				size_t dst_capacity, uint64_t *total_host);
 int oroch_container_decode_host(const void *src_host, size_t container_bytes, size_t first_block,
 				size_t nblocks, void *dst_host);
+
+/* ---- searching and random access over block images ------------------------------ */
+
+/*
+ * For each of the m values (device, raw bits zero-extended to 64) the lowest
+ * position in the n-value array encoded at src / offsets (as written by
+ * oroch_group_encode) that holds it, or OROCH_NOT_FOUND: integer_array<T>::find,
+ * integer_array.h:192-208, over all groups at once.  With m == 1 the blocks whose
+ * metadata rules the value out are not decoded (the width shortcut of
+ * integer_array.h:110-122).  index: m x uint64 (device).
+ */
+#define OROCH_NOT_FOUND (~(uint64_t) 0)
+int oroch_group_find(int dtype, const void *src, const uint64_t *offsets, size_t n,
+		     const uint64_t *values, size_t m, uint64_t *index, void *stream);
+/*
+ * dst[q] = value number index[q] of the array, for m positions (device):
+ * array_integer_group<T>::operator[], integer_array.h:64-69 (decode the group,
+ * pick one value), for a batch.  A position >= n yields 0.
+ */
+int oroch_group_at(int dtype, const void *src, const uint64_t *offsets, size_t n,
+		   const uint64_t *index, size_t m, void *dst, void *stream);
+
+/* ---- growable compressed array -------------------------------------------------- */
+
+/*
+ * integer_array<T>, integer_array.h:150-259: full 256-value groups are kept
+ * encoded (here: one stream of block images in device memory plus its offsets
+ * table; each image byte-identical to the group's integer_group<T>::encode),
+ * the last 0..255 values raw on the host.  All calls run on the device that is
+ * current, use the null stream and return when their work is done; values cross
+ * the ABI as raw bits zero-extended to 64.  A handle is not thread-safe.
+ */
+typedef struct oroch_array oroch_array;
+int oroch_array_create(int dtype, oroch_array **out);
+void oroch_array_destroy(oroch_array *array);
+/* integer_array.h:161-164 */
+uint64_t oroch_array_size(const oroch_array *array);
+/* integer_array.h:210-214; keeps the device memory for reuse */
+int oroch_array_clear(oroch_array *array);
+/*
+ * Bulk append of n values from device / host memory: every group that fills is
+ * encoded in one device pass.  (The reference grows by insert() alone.)
+ */
+int oroch_array_append(oroch_array *array, const void *src, size_t n);
+int oroch_array_append_host(oroch_array *array, const void *src_host, size_t n);
+/*
+ * integer_array.h:216-245.  index <= size, else OROCH_E_RANGE.  Below the tail
+ * every later group is decoded, shifted and encoded again, on the device.
+ */
+int oroch_array_insert(oroch_array *array, uint64_t index, uint64_t value);
+/*
+ * integer_array.h:192-208 for m values at once (host arrays): index_host[j] =
+ * first position of values_host[j] or OROCH_NOT_FOUND; groups first, then the tail.
+ */
+int oroch_array_find(oroch_array *array, const uint64_t *values_host, size_t m,
+		     uint64_t *index_host);
+/*
+ * integer_array.h:166-178 for m positions at once (host arrays); dst_host gets m
+ * elements of the array's type.  OROCH_E_RANGE if a position is >= size (the
+ * reference throws std::out_of_range).
+ */
+int oroch_array_at(oroch_array *array, const uint64_t *index_host, size_t m, void *dst_host);
+/* Values [first, first + count) into dst_host; OROCH_E_RANGE beyond size. */
+int oroch_array_read(oroch_array *array, uint64_t first, uint64_t count, void *dst_host);
+/*
+ * Copies the image of one group (what integer_group<T>::encode(aligned = true)
+ * writes for its 256 values, zero padded to a multiple of 16) to dst_host;
+ * *bytes receives its length, also when capacity is too small
+ * (OROCH_E_CAPACITY).  OROCH_E_RANGE if there is no such group.
+ */
+int oroch_array_image(const oroch_array *array, uint64_t group, void *dst_host, size_t capacity,
+		      uint64_t *bytes);
+/*
+ * The encoded groups as oroch_group_decode / oroch_group_find take them
+ * (device pointers, valid until the next modifying call) and the raw tail
+ * (host).  Any output pointer may be null.
+ */
+int oroch_array_view(const oroch_array *array, const void **stream, const uint64_t **offsets,
+		     uint64_t *nblocks, uint64_t *stream_bytes, const void **tail_host,
+		     uint64_t *ntail);
 
 /* ---- diagnostics ---------------------------------------------------------------- */
 

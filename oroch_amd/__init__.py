@@ -10,6 +10,8 @@ from .capi import (  # noqa: F401
     DTYPES,
     ENCODING_NAMES,
     GroupEncoder,
+    IntegerArray,
+    NOT_FOUND,
     OrochError,
     bitfor_decode,
     bitfor_encode,
@@ -23,6 +25,8 @@ from .capi import (  # noqa: F401
     group_bound,
     group_decode,
     group_decode_host,
+    group_find,
+    group_at,
     container_decode,
     container_decode_host,
     container_encode,

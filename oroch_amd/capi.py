@@ -90,6 +90,20 @@ def _load():
         "oroch_container_decode": (i, [vp, vp, sz, sz, vp, vp]),
         "oroch_container_encode_host": (i, [i, vp, sz, vp, sz, vp]),
         "oroch_container_decode_host": (i, [vp, sz, sz, sz, vp]),
+        "oroch_group_find": (i, [i, vp, vp, sz, vp, sz, vp, vp]),
+        "oroch_group_at": (i, [i, vp, vp, sz, vp, sz, vp, vp]),
+        "oroch_array_create": (i, [i, vp]),
+        "oroch_array_destroy": (None, [vp]),
+        "oroch_array_size": (u64, [vp]),
+        "oroch_array_clear": (i, [vp]),
+        "oroch_array_append": (i, [vp, vp, sz]),
+        "oroch_array_append_host": (i, [vp, vp, sz]),
+        "oroch_array_insert": (i, [vp, u64, u64]),
+        "oroch_array_find": (i, [vp, vp, sz, vp]),
+        "oroch_array_at": (i, [vp, vp, sz, vp]),
+        "oroch_array_read": (i, [vp, u64, u64, vp]),
+        "oroch_array_image": (i, [vp, u64, vp, sz, vp]),
+        "oroch_array_view": (i, [vp, vp, vp, vp, vp, vp, vp]),
         "oroch_hip_profile_start": (i, [i]),
         "oroch_hip_profile_stop": (i, [vp, vp]),
     }
@@ -447,3 +461,128 @@ def container_decode_host(c, first_block=0, nblocks=None):
     out = np.empty(max(hi - lo, 0), DTYPES[int(h["dtype"])])
     _check(lib.oroch_container_decode_host(c.ctypes.data, c.size, first_block, nblocks, out.ctypes.data))
     return out
+
+
+# ---- searching, random access, the growable array -----------------------------------------
+
+NOT_FOUND = (1 << 64) - 1
+
+
+def _raw_needles(values, code, device):
+    """Values of the element type -> their raw bits zero-extended to 64 (CUDA int64 tensor)."""
+    import torch
+
+    a = np.atleast_1d(np.asarray(values)).astype(DTYPES[code])
+    raw = a.view(np.dtype(DTYPES[code]).str.replace("i", "u")).astype(np.uint64)
+    return torch.from_numpy(raw.view(np.int64)).to(device)
+
+
+def group_find(stream, offsets, n, dtype, values):
+    """First position of each value in the encoded array (numpy uint64, NOT_FOUND if absent)."""
+    import torch
+
+    code = dtype_code(dtype)
+    needles = _raw_needles(values, code, stream.device)
+    out = torch.empty(needles.numel(), dtype=torch.int64, device=stream.device)
+    _check(lib.oroch_group_find(code, stream.data_ptr(), offsets.data_ptr(), n, needles.data_ptr(),
+                                needles.numel(), out.data_ptr(), _stream()))
+    return out.cpu().numpy().view(np.uint64)
+
+
+def group_at(stream, offsets, n, dtype, index):
+    """Values at the given positions (CUDA tensor of the element type)."""
+    import torch
+
+    code = dtype_code(dtype)
+    idx = torch.as_tensor(np.asarray(index, np.uint64).view(np.int64)).to(stream.device)
+    out = torch.empty(idx.numel(), dtype=_torch_dtype(code), device=stream.device)
+    _check(lib.oroch_group_at(code, stream.data_ptr(), offsets.data_ptr(), n, idx.data_ptr(),
+                              idx.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+class IntegerArray:
+    """oroch_array_* behind the names of the reference's integer_array<T>
+    (integer_array.h:150-259), plus the bulk forms."""
+
+    def __init__(self, dtype):
+        self.dtype = np.dtype(dtype)
+        self.code = dtype_code(self.dtype)
+        self._h = C.c_void_p()
+        _check(lib.oroch_array_create(self.code, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.oroch_array_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return lib.oroch_array_size(self._h)
+
+    size = __len__
+
+    def empty(self):
+        return len(self) == 0
+
+    def clear(self):
+        _check(lib.oroch_array_clear(self._h))
+
+    def append(self, values):
+        """numpy array (host) or CUDA tensor (device)."""
+        if hasattr(values, "data_ptr"):
+            assert dtype_code(values.dtype) == self.code and values.is_contiguous()
+            _check(lib.oroch_array_append(self._h, values.data_ptr(), values.numel()))
+        else:
+            a = np.ascontiguousarray(values, self.dtype)
+            _check(lib.oroch_array_append_host(self._h, a.ctypes.data, a.size))
+
+    def insert(self, index, value):
+        _check(lib.oroch_array_insert(self._h, index, _raw64(value, self.code)))
+
+    def find(self, values):
+        """One value -> its first position or NOT_FOUND; a sequence -> numpy uint64 array."""
+        a = np.atleast_1d(np.asarray(values)).astype(self.dtype)
+        raw = np.ascontiguousarray(a.view(self.dtype.str.replace("i", "u")).astype(np.uint64))
+        out = np.empty(raw.size, np.uint64)
+        _check(lib.oroch_array_find(self._h, raw.ctypes.data, raw.size, out.ctypes.data))
+        return int(out[0]) if np.ndim(values) == 0 else out
+
+    def at(self, index):
+        idx = np.ascontiguousarray(np.atleast_1d(index), np.uint64)
+        out = np.empty(idx.size, self.dtype)
+        _check(lib.oroch_array_at(self._h, idx.ctypes.data, idx.size, out.ctypes.data))
+        return out[0] if np.ndim(index) == 0 else out
+
+    __getitem__ = at
+
+    def read(self, first=0, count=None):
+        if count is None:
+            count = len(self) - first
+        out = np.empty(count, self.dtype)
+        _check(lib.oroch_array_read(self._h, first, count, out.ctypes.data))
+        return out
+
+    def view(self):
+        """(stream, offsets, tail): the encoded groups as CUDA tensors that alias the
+        array's device memory (uint8 / int64; valid until the next modifying call;
+        None when there is no group yet) and the raw tail as a numpy array."""
+        import torch
+
+        st, of, tl = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nb, sb, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib.oroch_array_view(self._h, C.byref(st), C.byref(of), C.byref(nb), C.byref(sb),
+                                    C.byref(tl), C.byref(nt)))
+        tail = np.empty(nt.value, self.dtype)
+        if nt.value:
+            C.memmove(tail.ctypes.data, tl.value, tail.nbytes)
+        if nb.value == 0:
+            return None, None, tail
+
+        class _Alias:
+            def __init__(self, ptr, count, typestr):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr,
+                                                 "data": (ptr, False), "version": 2}
+
+        stream = torch.as_tensor(_Alias(st.value, sb.value, "|u1"), device="cuda")
+        offsets = torch.as_tensor(_Alias(of.value, nb.value + 1, "<i8"), device="cuda")
+        return stream, offsets, tail

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "host_util.hpp"
 
 namespace oroch_hip {
 
@@ -132,6 +133,7 @@ extern "C" const char *oroch_hip_strerror(int code)
 	case OROCH_E_CAPACITY: return "destination or workspace too small";
 	case OROCH_E_ARGUMENT: return "null / misaligned pointer or inconsistent sizes";
 	case OROCH_E_NOGPU: return "no usable gfx950 HIP device";
+	case OROCH_E_RANGE: return "position outside the array";
 	}
 	if (code > 0)
 		return hipGetErrorString(hipError_t(code));
@@ -139,20 +141,6 @@ extern "C" const char *oroch_hip_strerror(int code)
 }
 
 namespace {
-
-struct dev_buf
-{
-	void *p = nullptr;
-	~dev_buf()
-	{
-		if (p)
-			(void) hipFree(p);
-	}
-	int alloc(size_t bytes)
-	{
-		return int(hipMalloc(&p, bytes ? bytes : 16));
-	}
-};
 
 // memcpy split over a few threads: one core moves 10-12 GB/s between pageable
 // and pinned memory, a fifth of what the link to the device carries.
@@ -207,10 +195,12 @@ struct staging
 };
 staging g_staging;
 
+} // namespace
+
 // Copies between pageable host memory and the device in chunks staged through
 // two pinned buffers, so the host memcpy of one chunk overlaps the DMA of the
 // other.
-int staged_copy(void *dst, const void *src, size_t bytes, bool to_device, hipStream_t st)
+int oroch_hip::staged_copy(void *dst, const void *src, size_t bytes, bool to_device, hipStream_t st)
 {
 	if (bytes == 0)
 		return 0;
@@ -269,7 +259,9 @@ int staged_copy(void *dst, const void *src, size_t bytes, bool to_device, hipStr
 	return rc;
 }
 
-} // namespace
+
+using oroch_hip::dev_buf;
+using oroch_hip::staged_copy;
 
 extern "C" int oroch_group_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
 				       size_t dst_capacity, uint64_t *offsets_host,

@@ -1,0 +1,666 @@
+// array.hip -- searching and random access over a stream of block images, and the
+// growable compressed array built on them.
+//
+// Reference behaviour reproduced here (paths below /root/reference/oroch):
+//   integer_array.h:64-69      operator[] of a group: decode the block, pick one value
+//   integer_array.h:71-136     find within a group, with the metadata width shortcut
+//   integer_array.h:150-245    integer_array: size, at, find, clear, insert
+//
+// The kernels keep the mapping of the block decoder: one 64-lane wavefront per
+// block, lane l holding values 4l .. 4l+3.
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "block.hpp"
+#include "decode_quad.hpp"
+#include "host_util.hpp"
+
+namespace oroch_hip {
+
+// Bits needed for x (0 for 0): integer_traits.h:44-60.
+template <typename C>
+__device__ __forceinline__ uint32_t used_bits(C x)
+{
+	if constexpr (sizeof(C) == 8)
+		return x ? 64u - uint32_t(__clzll((unsigned long long) x)) : 0u;
+	else
+		return x ? 32u - uint32_t(__clz(uint32_t(x))) : 0u;
+}
+
+// integer_array.h:85-126: can the block whose image starts at img hold the
+// value?  A bitpck block holds only values whose zigzag form fits nbits, a
+// bitfor block only values within 2^nbits above its origin, a naught block
+// only its origin.  Everything else has to be decoded to know.
+template <typename E>
+__device__ __forceinline__ bool may_hold(const uint32_t *img, typename E::C needle)
+{
+	using C = typename E::C;
+	const uint4 hw = *reinterpret_cast<const uint4 *>(img);
+	const uint64_t h0 = (uint64_t(uniform(hw.y)) << 32) | uniform(hw.x);
+	const uint64_t h1 = (uint64_t(uniform(hw.w)) << 32) | uniform(hw.z);
+	const uint32_t enc = uint32_t(h0) & 0xffu;
+	uint32_t p = 1;
+	if (enc == OROCH_BITPCK) {
+		const uint32_t nb = hdr_byte(h0, h1, p);
+		return used_bits<C>(zz<E>(needle)) <= nb;
+	}
+	if (enc == OROCH_NAUGHT || enc == OROCH_BITFOR) {
+		const C origin = unzz<E>(C(hdr_varint(h0, h1, p)) & E::MASK);
+		if (enc == OROCH_NAUGHT)
+			return needle == origin;
+		const uint32_t nb = hdr_byte(h0, h1, p);
+		return used_bits<C>(C((needle - origin) & E::MASK)) <= nb;
+	}
+	return true;
+}
+
+// Has a position below block blk been reported already?  (Blocks are walked in
+// rising order by every wavefront, so nothing it has left can improve on that.)
+__device__ __forceinline__ bool found_below(const unsigned long long *result, size_t blk)
+{
+	const uint64_t best = read_lane(uint64_t(__atomic_load_n(result, __ATOMIC_RELAXED)), 0);
+	const uint64_t here = uint64_t(blk) * BLOCK;
+	// 32-bit compares: see clamp_u64
+	const uint32_t bh = uint32_t(best >> 32), hh = uint32_t(here >> 32);
+	return bh < hh || (bh == hh && uint32_t(best) < uint32_t(here));
+}
+
+// Compares the block's values with every needle; a lane that holds one
+// reports its position by atomic minimum.
+template <typename E>
+__device__ __forceinline__ void report_hits(size_t blk, int nv, int lane, const typename E::C (&v)[VPL],
+					    const uint64_t *__restrict__ needles, size_t m,
+					    unsigned long long *result)
+{
+	using C = typename E::C;
+	for (size_t j = 0; j < m; j++) {
+		const C x = C(uniform(needles[j])) & E::MASK;
+		int hit = -1;
+#pragma unroll
+		for (int s = VPL - 1; s >= 0; s--)
+			if (v[s] == x && lane * VPL + s < nv)
+				hit = s;
+		if (hit >= 0)
+			atomicMin(&result[j],
+				  (unsigned long long) (uint64_t(blk) * BLOCK + uint64_t(lane * VPL + hit)));
+	}
+}
+
+// For each of m needles the lowest position holding it, by atomic minimum
+// into result[] (preset to all ones = not found).  With one needle the
+// wavefronts skip the blocks that cannot hold it and stop once a lower block
+// has produced a hit.
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_find(const uint8_t *__restrict__ src,
+							       const uint64_t *__restrict__ offsets,
+							       size_t n, size_t nblocks,
+							       const uint64_t *__restrict__ needles, size_t m,
+							       unsigned long long *result)
+{
+	using C = typename E::C;
+	const int lane = lane_id();
+	const C first = C(uniform(needles[0])) & E::MASK;
+	walk_blocks<E>(
+		src, offsets, n, nblocks,
+		[&](size_t blk, const uint32_t *img, uint32_t) {
+			if (m != 1)
+				return WALK_DECODE;
+			if (found_below(result, blk))
+				return WALK_STOP;
+			return may_hold<E>(img, first) ? WALK_DECODE : WALK_SKIP;
+		},
+		[&](size_t blk, int nv, const C(&v)[VPL]) { report_hits<E>(blk, nv, lane, v, needles, m, result); });
+}
+
+// The same on the four-blocks-per-wavefront decoder (element types up to 32
+// bits); blocks are not skipped there, decoding four at once costs less than
+// deciding.
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_find_quad(
+	const uint8_t *__restrict__ src, const uint64_t *__restrict__ offsets, size_t n, size_t nblocks,
+	const uint64_t *__restrict__ needles, size_t m, unsigned long long *result)
+{
+	using C = typename E::C;
+	walk_quads<E>(
+		src, offsets, n, nblocks,
+		[&](size_t blk) { return m == 1 && found_below(result, blk) ? WALK_STOP : WALK_DECODE; },
+		[&](size_t blk, int nv, int lane, const C(&v)[VPL]) {
+			report_hits<E>(blk, nv, lane, v, needles, m, result);
+		});
+}
+
+// Value number index[q] of the array for each of m queries: one wavefront per
+// query decodes the block that holds it.  A position at or beyond n yields 0.
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_at(const uint8_t *__restrict__ src,
+							     const uint64_t *__restrict__ offsets, size_t n,
+							     size_t nblocks, const uint64_t *__restrict__ index,
+							     size_t m, typename E::S *__restrict__ dst)
+{
+	using C = typename E::C;
+	using S = typename E::S;
+	constexpr uint32_t MAXLEN = uint32_t(image_bytes<E>() - 16);
+	constexpr int NCH = int((MAXLEN + 1023) / 1024);
+	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
+	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK + FIELDS_PAD];
+	__shared__ __attribute__((aligned(16))) C highs[WAVES_PER_WG][BLOCK];
+	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
+	__shared__ uint4 wt[65];
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	load_width_table(wt);
+	uint32_t *img = image[wave];
+	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+	const uint64_t limit = uniform(offsets[nblocks]);
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
+	for (size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave; q < m; q += stride) {
+		const uint64_t at = uniform(index[q]);
+		const uint32_t ah = uint32_t(at >> 32), nh = uint32_t(uint64_t(n) >> 32);
+		const bool inside = ah < nh || (ah == nh && uint32_t(at) < uint32_t(n));
+		if (!inside) {
+			if (lane == 0)
+				dst[q] = S(0);
+			continue;
+		}
+		const size_t blk = size_t(at / BLOCK);
+		const uint32_t pos = uint32_t(at % BLOCK);
+		const int nv = block_count(n, blk);
+		// the block's extent, confined to the stream as in walk_blocks
+		const uint64_t o = min_u64(uniform(offsets[blk]), limit) & ~uint64_t(15);
+		const uint64_t e = min_u64(uniform(offsets[blk + 1]), limit);
+		const uint32_t eh = uint32_t(e >> 32), oh = uint32_t(o >> 32);
+		const bool forward = eh > oh || (eh == oh && uint32_t(e) >= uint32_t(o));
+		const uint32_t len = forward ? clamp_u64(e - o, MAXLEN) : 0u;
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const uint32_t b = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+			uint4 x = make_uint4(0, 0, 0, 0);
+			if (b < len)
+				x = *reinterpret_cast<const uint4 *>(src + o + b);
+			if (b < len || b == 0)
+				*reinterpret_cast<uint4 *>(img8 + b) = x;
+		}
+		wave_sync();
+		C v[VPL];
+		if (nv == BLOCK)
+			decode_block<E, true>(img, len, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+		else
+			decode_block<E, false>(img, len, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+		if (uint32_t(lane) == pos / VPL) {
+			const uint32_t s = pos % VPL;
+			const C x = s == 0 ? v[0] : s == 1 ? v[1] : s == 2 ? v[2] : v[3];
+			dst[q] = S(x);
+		}
+		wave_sync();
+	}
+}
+
+// out[i] = in[i] + base: block offsets of a piece encoded at byte `base` of a
+// longer stream.
+__global__ void k_rebase(const uint64_t *in, size_t count, uint64_t base, uint64_t *out)
+{
+	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+	     i += size_t(gridDim.x) * blockDim.x)
+		out[i] = in[i] + base;
+}
+
+static unsigned walk_grid(size_t units)
+{
+	const size_t wgs = (units + WAVES_PER_WG - 1) / WAVES_PER_WG;
+	return unsigned(wgs < 16384 ? wgs : 16384);
+}
+
+} // namespace oroch_hip
+
+using namespace oroch_hip;
+
+extern "C" int oroch_group_find(int dtype, const void *src, const uint64_t *offsets, size_t n,
+				const uint64_t *values, size_t m, uint64_t *index, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (m == 0)
+		return 0;
+	if (!values || !index || (n && (!src || !offsets)) || (reinterpret_cast<uintptr_t>(src) & 15u))
+		return OROCH_E_ARGUMENT;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	int rc = int(hipMemsetAsync(index, 0xff, m * sizeof(uint64_t), st));
+	const size_t nb = (n + BLOCK - 1) / BLOCK;
+	if (rc || nb == 0)
+		return rc;
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		if constexpr (sizeof(typename E::C) == 4) {
+			// OROCH_HIP_FIND_ONE_BLOCK=1 keeps to the one-block walker (tests)
+			const char *v = getenv("OROCH_HIP_FIND_ONE_BLOCK");
+			if (!(v && *v && *v != '0')) {
+				hipLaunchKernelGGL(k_find_quad<E>, dim3(walk_grid((nb + QUAD - 1) / QUAD)),
+						   dim3(WAVE * WAVES_PER_WG), 0, st, static_cast<const uint8_t *>(src),
+						   offsets, n, nb, values, m, reinterpret_cast<unsigned long long *>(index));
+				return int(hipGetLastError());
+			}
+		}
+		hipLaunchKernelGGL(k_find<E>, dim3(walk_grid(nb)), dim3(WAVE * WAVES_PER_WG), 0, st,
+				   static_cast<const uint8_t *>(src), offsets, n, nb, values, m,
+				   reinterpret_cast<unsigned long long *>(index));
+		return int(hipGetLastError());
+	});
+}
+
+extern "C" int oroch_group_at(int dtype, const void *src, const uint64_t *offsets, size_t n,
+			      const uint64_t *index, size_t m, void *dst, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (m == 0)
+		return 0;
+	if (!index || !dst || !offsets || (n && !src) || (reinterpret_cast<uintptr_t>(src) & 15u))
+		return OROCH_E_ARGUMENT;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const size_t nb = (n + BLOCK - 1) / BLOCK;
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		hipLaunchKernelGGL(k_at<E>, dim3(walk_grid(m)), dim3(WAVE * WAVES_PER_WG), 0, st,
+				   static_cast<const uint8_t *>(src), offsets, n, nb, index, m,
+				   static_cast<typename E::S *>(dst));
+		return int(hipGetLastError());
+	});
+}
+
+// ---- the growable array -----------------------------------------------------------------
+//
+// Full blocks live in device memory as one stream of block images plus the
+// table of their offsets; the last 0..255 values wait on the host until they
+// fill a block (integer_array.h:255-258 keeps the same split, with one heap
+// buffer per group).
+
+struct oroch_array
+{
+	int dtype = 0;
+	size_t nblocks = 0;      // block images in the stream
+	size_t stream_bytes = 0; // = offsets[nblocks]
+	dev_buf stream;
+	size_t stream_cap = 0;   // bytes
+	dev_buf offsets;
+	size_t offsets_cap = 0;  // entries
+	dev_buf small;           // needles, positions and results of one query batch
+	size_t small_cap = 0;    // bytes
+	std::vector<uint8_t> tail; // raw values not yet in a block
+
+	size_t width() const
+	{
+		return size_t(1) << (dtype >> 1);
+	}
+	size_t in_blocks() const
+	{
+		return nblocks * size_t(BLOCK);
+	}
+	size_t in_tail() const
+	{
+		return tail.size() / width();
+	}
+};
+
+namespace {
+
+// Makes buf hold at least `need` bytes, keeping the first `keep`.
+int grow(dev_buf &buf, size_t &cap, size_t need, size_t keep)
+{
+	if (need <= cap)
+		return 0;
+	size_t want = cap * 2 > need ? cap * 2 : need;
+	want = (want + 255) & ~size_t(255);
+	dev_buf bigger;
+	int rc = bigger.alloc(want);
+	if (rc)
+		return rc;
+	if (keep && (rc = int(hipMemcpy(bigger.p, buf.p, keep, hipMemcpyDeviceToDevice))))
+		return rc;
+	buf.swap(bigger);
+	cap = want;
+	return 0;
+}
+
+int small_buffer(oroch_array *a, size_t bytes)
+{
+	return grow(a->small, a->small_cap, bytes, 0);
+}
+
+// Appends count values (a multiple of 256, device memory) as new blocks.
+int encode_blocks(oroch_array *a, const void *d_values, size_t count)
+{
+	if (count == 0)
+		return 0;
+	const size_t nb = count / BLOCK;
+	const size_t bound = oroch_group_bound(a->dtype, count);
+	const size_t wsb = oroch_group_workspace(a->dtype, count);
+	int rc;
+	if ((rc = grow(a->stream, a->stream_cap, a->stream_bytes + bound, a->stream_bytes)) ||
+	    (rc = grow(a->offsets, a->offsets_cap, (a->nblocks + nb + 1) * sizeof(uint64_t),
+		       a->nblocks ? (a->nblocks + 1) * sizeof(uint64_t) : 0)))
+		return rc;
+	dev_buf piece, ws;
+	if ((rc = piece.alloc((nb + 1) * sizeof(uint64_t))) || (rc = ws.alloc(wsb)))
+		return rc;
+	uint64_t total = 0;
+	rc = oroch_group_encode(a->dtype, d_values, count, static_cast<uint8_t *>(a->stream.p) + a->stream_bytes,
+				bound, static_cast<uint64_t *>(piece.p), ws.p, wsb, &total, nullptr);
+	if (rc)
+		return rc;
+	const unsigned grid = unsigned((nb + 1 + 255) / 256 < 1024 ? (nb + 1 + 255) / 256 : 1024);
+	hipLaunchKernelGGL(k_rebase, dim3(grid), dim3(256), 0, nullptr, static_cast<const uint64_t *>(piece.p),
+			   nb + 1, uint64_t(a->stream_bytes), static_cast<uint64_t *>(a->offsets.p) + a->nblocks);
+	if ((rc = int(hipGetLastError())) || (rc = int(hipStreamSynchronize(nullptr))))
+		return rc;
+	a->stream_bytes += total;
+	a->nblocks += nb;
+	return 0;
+}
+
+// Moves a full tail (256 values) into the stream.
+int flush_tail(oroch_array *a)
+{
+	if (a->in_tail() < size_t(BLOCK))
+		return 0;
+	dev_buf in;
+	int rc;
+	if ((rc = in.alloc(a->tail.size())) ||
+	    (rc = int(hipMemcpy(in.p, a->tail.data(), a->tail.size(), hipMemcpyHostToDevice))) ||
+	    (rc = encode_blocks(a, in.p, BLOCK)))
+		return rc;
+	a->tail.clear();
+	return 0;
+}
+
+int append_any(oroch_array *a, const void *src, size_t n, bool src_on_device)
+{
+	if (n == 0)
+		return 0;
+	const size_t w = a->width();
+	const size_t held = a->in_tail();
+	const size_t full = (held + n) / BLOCK * BLOCK; // values that go into blocks now
+	const uint8_t *from = static_cast<const uint8_t *>(src);
+	int rc = 0;
+	size_t taken = 0; // values of src that went into blocks
+	if (full) {
+		taken = full - held;
+		if (held == 0 && src_on_device) {
+			rc = encode_blocks(a, src, full);
+		} else {
+			dev_buf in;
+			if ((rc = in.alloc(full * w)))
+				return rc;
+			uint8_t *d = static_cast<uint8_t *>(in.p);
+			if (held)
+				rc = int(hipMemcpy(d, a->tail.data(), held * w, hipMemcpyHostToDevice));
+			if (rc == 0)
+				rc = src_on_device ? int(hipMemcpy(d + held * w, from, taken * w, hipMemcpyDeviceToDevice))
+						   : staged_copy(d + held * w, from, taken * w, true, nullptr);
+			if (rc == 0)
+				rc = encode_blocks(a, d, full);
+		}
+		if (rc)
+			return rc;
+		a->tail.clear();
+	}
+	const size_t rest = n - taken; // < 256 once blocks were cut, else all of src
+	if (rest) {
+		const size_t at = a->tail.size();
+		a->tail.resize(at + rest * w);
+		if (src_on_device)
+			rc = int(hipMemcpy(a->tail.data() + at, from + taken * w, rest * w, hipMemcpyDeviceToHost));
+		else
+			std::memcpy(a->tail.data() + at, from + taken * w, rest * w);
+	}
+	return rc;
+}
+
+uint64_t tail_value(const oroch_array *a, size_t i)
+{
+	uint64_t x = 0;
+	std::memcpy(&x, a->tail.data() + i * a->width(), a->width()); // little endian host
+	return x;
+}
+
+} // namespace
+
+extern "C" int oroch_array_create(int dtype, oroch_array **out)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (!out)
+		return OROCH_E_ARGUMENT;
+	oroch_array *a = new (std::nothrow) oroch_array;
+	if (!a)
+		return int(hipErrorOutOfMemory);
+	a->dtype = dtype;
+	*out = a;
+	return 0;
+}
+
+extern "C" void oroch_array_destroy(oroch_array *a)
+{
+	delete a;
+}
+
+extern "C" uint64_t oroch_array_size(const oroch_array *a)
+{
+	return a ? a->in_blocks() + a->in_tail() : 0;
+}
+
+extern "C" int oroch_array_clear(oroch_array *a)
+{
+	if (!a)
+		return OROCH_E_ARGUMENT;
+	a->nblocks = 0;
+	a->stream_bytes = 0;
+	a->tail.clear();
+	return 0;
+}
+
+extern "C" int oroch_array_append(oroch_array *a, const void *src, size_t n)
+{
+	if (!a || (n && !src))
+		return OROCH_E_ARGUMENT;
+	return append_any(a, src, n, true);
+}
+
+extern "C" int oroch_array_append_host(oroch_array *a, const void *src_host, size_t n)
+{
+	if (!a || (n && !src_host))
+		return OROCH_E_ARGUMENT;
+	return append_any(a, src_host, n, false);
+}
+
+extern "C" int oroch_array_view(const oroch_array *a, const void **stream, const uint64_t **offsets,
+				uint64_t *nblocks, uint64_t *stream_bytes, const void **tail_host,
+				uint64_t *ntail)
+{
+	if (!a)
+		return OROCH_E_ARGUMENT;
+	if (stream)
+		*stream = a->nblocks ? a->stream.p : nullptr;
+	if (offsets)
+		*offsets = a->nblocks ? static_cast<const uint64_t *>(a->offsets.p) : nullptr;
+	if (nblocks)
+		*nblocks = a->nblocks;
+	if (stream_bytes)
+		*stream_bytes = a->stream_bytes;
+	if (tail_host)
+		*tail_host = a->tail.data();
+	if (ntail)
+		*ntail = a->in_tail();
+	return 0;
+}
+
+extern "C" int oroch_array_image(const oroch_array *a, uint64_t group, void *dst_host, size_t capacity,
+				 uint64_t *bytes)
+{
+	if (!a || !bytes)
+		return OROCH_E_ARGUMENT;
+	if (group >= a->nblocks)
+		return OROCH_E_RANGE;
+	uint64_t ext[2];
+	int rc = int(hipMemcpy(ext, static_cast<const uint64_t *>(a->offsets.p) + group, sizeof(ext),
+			       hipMemcpyDeviceToHost));
+	if (rc)
+		return rc;
+	*bytes = ext[1] - ext[0];
+	if (*bytes > capacity)
+		return OROCH_E_CAPACITY;
+	if (!dst_host)
+		return OROCH_E_ARGUMENT;
+	return int(hipMemcpy(dst_host, static_cast<const uint8_t *>(a->stream.p) + ext[0], size_t(*bytes),
+			     hipMemcpyDeviceToHost));
+}
+
+extern "C" int oroch_array_find(oroch_array *a, const uint64_t *values, size_t m, uint64_t *index)
+{
+	if (!a || (m && (!values || !index)))
+		return OROCH_E_ARGUMENT;
+	if (m == 0)
+		return 0;
+	for (size_t j = 0; j < m; j++)
+		index[j] = ~uint64_t(0);
+	int rc;
+	if (a->nblocks) {
+		if ((rc = small_buffer(a, 2 * m * sizeof(uint64_t))))
+			return rc;
+		uint64_t *d_values = static_cast<uint64_t *>(a->small.p), *d_index = d_values + m;
+		if ((rc = int(hipMemcpy(d_values, values, m * sizeof(uint64_t), hipMemcpyHostToDevice))) ||
+		    (rc = oroch_group_find(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p),
+					   a->in_blocks(), d_values, m, d_index, nullptr)) ||
+		    (rc = int(hipMemcpy(index, d_index, m * sizeof(uint64_t), hipMemcpyDeviceToHost))))
+			return rc;
+	}
+	// integer_array.h:202-205: the tail is searched last
+	const size_t held = a->in_tail();
+	const uint64_t mask = a->width() == 8 ? ~uint64_t(0) : (uint64_t(1) << (8 * a->width())) - 1;
+	for (size_t j = 0; j < m && held; j++) {
+		if (index[j] != ~uint64_t(0))
+			continue;
+		for (size_t i = 0; i < held; i++) {
+			if (tail_value(a, i) == (values[j] & mask)) {
+				index[j] = a->in_blocks() + i;
+				break;
+			}
+		}
+	}
+	return 0;
+}
+
+extern "C" int oroch_array_at(oroch_array *a, const uint64_t *index, size_t m, void *dst_host)
+{
+	if (!a || (m && (!index || !dst_host)))
+		return OROCH_E_ARGUMENT;
+	const size_t size = a->in_blocks() + a->in_tail(), w = a->width();
+	bool any_block = false;
+	for (size_t q = 0; q < m; q++) {
+		if (index[q] >= size)
+			return OROCH_E_RANGE;
+		any_block |= index[q] < a->in_blocks();
+	}
+	int rc;
+	if (any_block) {
+		const size_t ibytes = m * sizeof(uint64_t);
+		if ((rc = small_buffer(a, ibytes + m * w)))
+			return rc;
+		uint64_t *d_index = static_cast<uint64_t *>(a->small.p);
+		void *d_out = static_cast<uint8_t *>(a->small.p) + ibytes;
+		if ((rc = int(hipMemcpy(d_index, index, ibytes, hipMemcpyHostToDevice))) ||
+		    (rc = oroch_group_at(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p),
+					 a->in_blocks(), d_index, m, d_out, nullptr)) ||
+		    (rc = int(hipMemcpy(dst_host, d_out, m * w, hipMemcpyDeviceToHost))))
+			return rc;
+	}
+	for (size_t q = 0; q < m; q++) {
+		if (index[q] >= a->in_blocks())
+			std::memcpy(static_cast<uint8_t *>(dst_host) + q * w,
+				    a->tail.data() + (index[q] - a->in_blocks()) * w, w);
+	}
+	return 0;
+}
+
+extern "C" int oroch_array_read(oroch_array *a, uint64_t first, uint64_t count, void *dst_host)
+{
+	if (!a || (count && !dst_host))
+		return OROCH_E_ARGUMENT;
+	const size_t size = a->in_blocks() + a->in_tail(), w = a->width();
+	if (first > size || count > size - first)
+		return OROCH_E_RANGE;
+	uint8_t *out = static_cast<uint8_t *>(dst_host);
+	const uint64_t stop = first + count;
+	const uint64_t bstop = stop < a->in_blocks() ? stop : a->in_blocks();
+	if (first < bstop) {
+		const size_t b0 = first / BLOCK, b1 = (bstop + BLOCK - 1) / BLOCK;
+		const size_t nv = (b1 - b0) * BLOCK;
+		dev_buf vals;
+		int rc;
+		if ((rc = vals.alloc(nv * w)) ||
+		    (rc = oroch_group_decode(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p) + b0,
+					     nv, vals.p, nullptr)) ||
+		    (rc = staged_copy(out, static_cast<uint8_t *>(vals.p) + (first - b0 * BLOCK) * w,
+				      (bstop - first) * w, false, nullptr)))
+			return rc;
+	}
+	if (stop > a->in_blocks()) {
+		const uint64_t t0 = first > a->in_blocks() ? first - a->in_blocks() : 0;
+		const uint64_t skip = first > a->in_blocks() ? 0 : a->in_blocks() - first;
+		std::memcpy(out + skip * w, a->tail.data() + t0 * w, (stop - a->in_blocks() - t0) * w);
+	}
+	return 0;
+}
+
+// integer_array.h:216-245.  An insertion below the tail moves every later
+// value up by one: the blocks from the insertion point on are decoded, shifted
+// on the device and encoded again; the value pushed out of the last block
+// becomes the first of the tail.
+extern "C" int oroch_array_insert(oroch_array *a, uint64_t index, uint64_t value)
+{
+	if (!a)
+		return OROCH_E_ARGUMENT;
+	const size_t w = a->width();
+	if (index > a->in_blocks() + a->in_tail())
+		return OROCH_E_RANGE;
+	uint8_t raw[8];
+	std::memcpy(raw, &value, 8); // little endian host
+	int rc;
+	if (index >= a->in_blocks()) {
+		a->tail.insert(a->tail.begin() + (index - a->in_blocks()) * w, raw, raw + w);
+		return flush_tail(a);
+	}
+	const size_t g = index / BLOCK, at = index - g * BLOCK;
+	const size_t cnt = (a->nblocks - g) * BLOCK;
+	dev_buf vals, moved;
+	uint64_t cut = 0;
+	if ((rc = vals.alloc(cnt * w)) || (rc = moved.alloc((cnt + 1) * w)) ||
+	    (rc = oroch_group_decode(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p) + g, cnt,
+				     vals.p, nullptr)) ||
+	    (rc = int(hipMemcpy(&cut, static_cast<const uint64_t *>(a->offsets.p) + g, sizeof(cut),
+				hipMemcpyDeviceToHost))))
+		return rc;
+	uint8_t *v = static_cast<uint8_t *>(vals.p), *mv = static_cast<uint8_t *>(moved.p);
+	uint8_t last[8];
+	if ((at && (rc = int(hipMemcpy(mv, v, at * w, hipMemcpyDeviceToDevice)))) ||
+	    (rc = int(hipMemcpy(mv + at * w, raw, w, hipMemcpyHostToDevice))) ||
+	    (rc = int(hipMemcpy(mv + (at + 1) * w, v + at * w, (cnt - at) * w, hipMemcpyDeviceToDevice))) ||
+	    (rc = int(hipMemcpy(last, mv + cnt * w, w, hipMemcpyDeviceToHost))))
+		return rc;
+	// room for the new images first, so that a failed allocation leaves the
+	// array as it was
+	if ((rc = grow(a->stream, a->stream_cap, size_t(cut) + oroch_group_bound(a->dtype, cnt), a->stream_bytes)))
+		return rc;
+	const size_t old_blocks = a->nblocks, old_bytes = a->stream_bytes;
+	a->nblocks = g;
+	a->stream_bytes = size_t(cut);
+	if ((rc = encode_blocks(a, mv, cnt))) {
+		if (a->nblocks == g) {
+			a->nblocks = old_blocks;
+			a->stream_bytes = old_bytes;
+		}
+		return rc;
+	}
+	a->tail.insert(a->tail.begin(), last, last + w);
+	return flush_tail(a);
+}

@@ -1,0 +1,478 @@
+// block.hpp -- what the kernels that work on 256-value blocks share: the lane
+// layout (one 64-lane wavefront per block, lane l holds values 4l .. 4l+3),
+// loading and storing a block, decoding a block image, and the persistent loop
+// that walks the block images of a stream.
+//
+// Reference behaviour reproduced here (paths below /root/reference/oroch):
+//   integer_codec.h:153-214, 498-609       metadata bytes, decode dispatch, bitpfr lists
+//   integer_group.h:62-76                  [meta][pad to 8][data] framing
+//   bitpck.h:171-201, varint.h:85-115      16-byte block unpacking, varints
+#pragma once
+
+#include "common.hpp"
+#include "bitfield.hpp"
+
+namespace oroch_hip {
+
+constexpr int VPL = 4;                     // values per lane
+constexpr int BLOCK = WAVE * VPL;          // values per block (256)
+constexpr int WAVES_PER_WG = 4;
+
+static_assert(BLOCK == OROCH_BLOCK_VALUES, "block size mismatch");
+static_assert(sizeof(oroch_block_desc) == 32, "descriptor layout");
+
+// min(x, cap) for a 64-bit x and a small cap, written with 32-bit compares:
+// there is no scalar 64-bit less-than on this target, and the vector compare
+// the compiler substitutes for a wave-uniform one has been seen paired with a
+// scalar select on a stale condition bit.
+__device__ __forceinline__ uint32_t clamp_u64(uint64_t x, uint32_t cap)
+{
+	const uint32_t lo = uint32_t(x), hi = uint32_t(x >> 32);
+	return hi ? cap : (lo < cap ? lo : cap);
+}
+// min(a, b) of two wave-uniform 64-bit values, on 32-bit compares for the same reason.
+__device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b)
+{
+	const uint32_t ah = uint32_t(a >> 32), bh = uint32_t(b >> 32);
+	const bool less = ah < bh || (ah == bh && uint32_t(a) < uint32_t(b));
+	return less ? a : b;
+}
+// Values in block number blk of an n-value array.
+__device__ __forceinline__ int block_count(size_t n, size_t blk)
+{
+	return int(clamp_u64(uint64_t(n) - uint64_t(blk) * BLOCK, uint32_t(BLOCK)));
+}
+
+// Bytes of LDS one wavefront needs for its block image: the largest image is
+// the raw copy (8 + 256 * sizeof T); the decoder also uses it as value
+// scratch.  Three spare dwords let bit reads run past the last byte.
+template <typename E>
+constexpr int image_bytes()
+{
+	return ((8 + BLOCK * E::BYTES + 15) / 16) * 16 + 16;
+}
+
+// ---- loading a block --------------------------------------------------------
+
+template <typename E>
+__device__ __forceinline__ void load_block(const typename E::S *src, size_t base, int nv, int lane,
+					   typename E::C (&v)[VPL])
+{
+	using S = typename E::S;
+	using C = typename E::C;
+	const S *p = src + base + size_t(lane) * VPL;
+	if (lane * VPL + VPL <= nv) {
+		// one vector load per lane: 4, 8, 16 or 32 bytes
+		if constexpr (E::BYTES == 8) {
+			const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p);
+			ulonglong2 a = q[0], b = q[1];
+			v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+		} else if constexpr (E::BYTES == 4) {
+			uint4 a = *reinterpret_cast<const uint4 *>(p);
+			v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+		} else if constexpr (E::BYTES == 2) {
+			uint2 a = *reinterpret_cast<const uint2 *>(p);
+			v[0] = a.x & 0xffffu; v[1] = a.x >> 16; v[2] = a.y & 0xffffu; v[3] = a.y >> 16;
+		} else {
+			uint32_t a = *reinterpret_cast<const uint32_t *>(p);
+			v[0] = a & 0xffu; v[1] = (a >> 8) & 0xffu; v[2] = (a >> 16) & 0xffu; v[3] = a >> 24;
+		}
+	} else {
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			v[s] = lane * VPL + s < nv ? C(p[s]) : C(0);
+	}
+}
+
+template <typename E>
+__device__ __forceinline__ void store_block(typename E::S *dst, size_t base, int nv, int lane,
+					    const typename E::C (&v)[VPL])
+{
+	using S = typename E::S;
+	S *p = dst + base + size_t(lane) * VPL;
+	if (lane * VPL + VPL <= nv) {
+		if constexpr (E::BYTES == 8) {
+			ulonglong2 *q = reinterpret_cast<ulonglong2 *>(p);
+			q[0] = make_ulonglong2(v[0], v[1]);
+			q[1] = make_ulonglong2(v[2], v[3]);
+		} else if constexpr (E::BYTES == 4) {
+			*reinterpret_cast<uint4 *>(p) = make_uint4(v[0], v[1], v[2], v[3]);
+		} else if constexpr (E::BYTES == 2) {
+			*reinterpret_cast<uint2 *>(p) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+		} else {
+			*reinterpret_cast<uint32_t *>(p) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+		}
+	} else {
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			if (lane * VPL + s < nv)
+				p[s] = S(v[s]);
+	}
+}
+
+// ---- decode -------------------------------------------------------------------------
+
+// varint.h:85-115 at a byte position of an LDS image; advances pos.
+__device__ __forceinline__ uint64_t get_varint(const uint8_t *img, uint32_t &pos)
+{
+	uint64_t value = 0;
+	uint32_t shift = 0;
+	for (;;) {
+		uint32_t byte = img[pos++];
+		if (shift < 64)
+			value |= uint64_t(byte & 0x7fu) << shift;
+		shift += 7;
+		if ((byte & 0x80u) == 0 || shift > 70)
+			break;
+	}
+	return value;
+}
+
+// Decodes `count` varints that start at byte `start` of the image, lanes
+// working on 64 bytes at a time: a byte that ends a value (top bit clear)
+// closes one; every byte ORs its 7 payload bits into its value's slot of
+// `out` (LDS, zero filled by the caller).  Returns the bytes consumed.
+template <typename C>
+__device__ uint32_t varint_list_decode(const uint8_t *img8, uint32_t start, uint32_t limit,
+				       uint32_t count, C *out, int lane)
+{
+	uint32_t done = 0;   // values completed so far
+	uint32_t carry = 0;  // bytes of the open value seen in earlier chunks
+	uint32_t pos = start;
+	while (done < count && pos < limit) {
+		const uint32_t at = pos + uint32_t(lane);
+		const uint32_t byte = at < limit ? img8[at] : 0u;
+		const bool term = (byte & 0x80u) == 0;
+		const uint64_t T = __ballot(term);
+		const uint64_t below = T & ((uint64_t(1) << lane) - 1);
+		const uint32_t r = uint32_t(__popcll(below));
+		const int pt = below ? 63 - __clzll(below) : -1;
+		const uint32_t k = uint32_t(lane - pt - 1) + (pt < 0 ? carry : 0u);
+		const uint32_t vi = done + r;
+		if (vi < count && k * 7u < sizeof(C) * 8u) {
+			C part = C(byte & 0x7fu) << (k * 7u);
+			if (part) {
+				if constexpr (sizeof(C) == 8)
+					atomicOr(reinterpret_cast<unsigned long long *>(&out[vi]),
+						 (unsigned long long) part);
+				else
+					atomicOr(&out[vi], part);
+			}
+		}
+		// how far does this chunk go: up to the terminator that completes
+		// value `count`, else all 64 bytes
+		const uint32_t nterm = uint32_t(__popcll(T));
+		if (done + nterm >= count) {
+			// position of the (count - done)-th terminator
+			uint32_t need = count - done;
+			uint64_t t = T;
+			for (uint32_t i = 1; i < need; i++)
+				t &= t - 1;
+			pos += uint32_t(__builtin_ctzll(t)) + 1u;
+			done = count;
+		} else {
+			const int last = T ? 63 - __clzll(T) : -1;
+			carry = last < 0 ? carry + 64u : uint32_t(63 - last);
+			done += nterm;
+			pos += 64u;
+		}
+	}
+	wave_sync();
+	return pos - start;
+}
+
+
+// Byte p (0..15) of a 16-byte header held in two scalar registers.  (Plain
+// variables, not an array: a dynamically indexed private array is moved to
+// memory by the compiler and everything derived from it stops being scalar.)
+__device__ __forceinline__ uint32_t hdr_byte(uint64_t h0, uint64_t h1, uint32_t p)
+{
+	const uint64_t w = (p & 8u) ? h1 : h0;
+	return uint32_t(w >> ((p & 7u) * 8u)) & 0xffu;
+}
+// varint.h:85-115 from the header registers; advances p.
+__device__ __forceinline__ uint64_t hdr_varint(uint64_t h0, uint64_t h1, uint32_t &p)
+{
+	uint64_t value = 0;
+	uint32_t shift = 0;
+	for (;;) {
+		const uint32_t byte = hdr_byte(h0, h1, p);
+		p++;
+		if (shift < 64)
+			value |= uint64_t(byte & 0x7fu) << shift;
+		shift += 7;
+		if ((byte & 0x80u) == 0 || shift > 70)
+			break;
+	}
+	return value;
+}
+
+// Decodes the block whose image (len bytes) sits in `img`.  FULL: 256 values.
+template <typename E, bool FULL>
+__device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv, int lane, typename E::C *val,
+			     typename E::C *hv, uint32_t *gp, const uint4 *wt, typename E::C (&v)[VPL])
+{
+	using C = typename E::C;
+	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+
+	// metadata, integer_codec.h:153-175, 184-194, 206-214: the first 16 bytes,
+	// read once and parsed in scalar registers
+	const uint4 hw = *reinterpret_cast<const uint4 *>(img);
+	const uint64_t h0 = (uint64_t(uniform(hw.y)) << 32) | uniform(hw.x);
+	const uint64_t h1 = (uint64_t(uniform(hw.w)) << 32) | uniform(hw.z);
+	uint32_t p = 1;
+	const uint32_t enc = uint32_t(h0) & 0xffu;
+	C origin = 0;
+	uint32_t nb = 0, nout = 0, inb = 0, vnb = 0;
+	if (enc == OROCH_NAUGHT || enc == OROCH_VARFOR || enc == OROCH_BITFOR || enc == OROCH_BITPFR)
+		origin = unzz<E>(C(hdr_varint(h0, h1, p)) & E::MASK);
+	if (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR)
+		nb = hdr_byte(h0, h1, p++);
+	if (enc == OROCH_BITPFR) {
+		nout = uint32_t(hdr_varint(h0, h1, p));
+		inb = hdr_byte(h0, h1, p++);
+		vnb = hdr_byte(h0, h1, p++);
+	}
+	const uint32_t doff = (p + 7u) & ~7u; // integer_group.h:70-72
+
+#pragma unroll
+	for (int s = 0; s < VPL; s++)
+		v[s] = 0;
+
+	// Reject what the encoder never produces instead of reading wild.
+	const bool sane = (nb >= 1 && nb <= uint32_t(E::W)) || !(enc >= OROCH_BITPCK);
+	if (enc == OROCH_NAUGHT) {
+		// naught.h:42-47
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			v[s] = origin;
+	} else if (enc == OROCH_NORMAL) {
+		// normal.h:51-58
+		const typename E::S *raw = reinterpret_cast<const typename E::S *>(img8 + doff);
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			if (FULL || lane * VPL + s < nv)
+				v[s] = raw[lane * VPL + s];
+	} else if ((enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) && sane) {
+		// bitpck.h:171-201.  Unpacked values go to val[] (one slot per value),
+		// exceptions are OR-ed into their slots there, then every lane picks up
+		// its four values.
+		if (nb >= uint32_t(FIELDS_MIN_NB)) {
+			// lane j unpacks packed block j with compile-time field positions
+			const uint32_t nblk = pck_space(wt, uint32_t(nv), nb) >> 4;
+			// (widths above 32 bits have more than 64 packed blocks)
+			for (uint32_t j = uint32_t(lane); j < nblk; j += WAVE) {
+				const uint2 *q = reinterpret_cast<const uint2 *>(img8 + doff) + j * 2;
+				const uint2 a = q[0], b = q[1];
+				const uint32_t w[4] = {a.x, a.y, b.x, b.y};
+				unpack_dispatch<C, FIELDS_MIN_NB, E::W>(nb, w, val, int(j));
+			}
+		} else {
+			// narrow fields: one value per lane and step
+			const uint4 we = wt[nb];
+			const uint32_t cap = uniform(we.x), m16 = uniform(we.z);
+#pragma unroll
+			for (int s = 0; s < VPL; s++) {
+				const uint32_t pos = uint32_t(lane * VPL + s);
+				const uint32_t blkn = (pos * m16) >> 16;
+				const uint32_t k = pos - blkn * cap;
+				C x = 0;
+				if (FULL || pos < uint32_t(nv))
+					x = lds_get_bits<C>(img, doff * 8u + blkn * 128u + k * nb, nb) & E::MASK;
+				val[pos] = x;
+			}
+		}
+		wave_sync();
+		if (enc == OROCH_BITPFR && nout > 0 && nout <= uint32_t(nv) && vnb <= uint32_t(E::W) &&
+		    inb <= 64) {
+			// integer_codec.h:583-609, bitpfr.h:114-124
+			const uint32_t ibase = doff + pck_space(wt, uint32_t(nv), nb);
+			// varint lists are assembled by OR into zeroed LDS slots
+			if (!inb || !vnb) {
+				for (uint32_t i = uint32_t(lane); i < nout; i += WAVE) {
+					hv[i] = 0;
+					gp[i] = 0;
+				}
+				wave_sync();
+			}
+			const uint32_t ilen = inb ? pck_space(wt, nout, inb)
+						  : varint_list_decode<uint32_t>(img8, ibase, len, nout, gp, lane);
+			const uint32_t vbase = ibase + ilen;
+			if (!vnb)
+				varint_list_decode<C>(img8, vbase, len, nout, hv, lane);
+			const uint4 iw = wt[inb ? inb : 1u], vw = wt[vnb ? vnb : 1u];
+			const uint32_t icap = uniform(iw.x), imagic = uniform(iw.y);
+			const uint32_t vcap = uniform(vw.x), vmagic = uniform(vw.y);
+			// positions: running sum of gap + 1 (offset.h:62-67); every
+			// exception ORs its high part into the slot of its position
+			uint32_t carry = 0;
+#pragma unroll
+			for (int it = 0; it < VPL; it++) {
+				if (uint32_t(it * WAVE) < nout) {
+					const uint32_t e = uint32_t(it * WAVE + lane);
+					uint32_t step = 0;
+					if (e < nout) {
+						if (inb) {
+							const uint32_t bk = __umulhi(e, imagic);
+							step = uint32_t(lds_get_bits64(img, ibase * 8u + bk * 128u +
+												    (e - bk * icap) * inb, inb));
+						} else {
+							step = gp[e];
+						}
+						step += 1u;
+					}
+					const uint32_t incl = wave_scan_sum(step, lane) + carry;
+					carry = read_lane(incl, WAVE - 1);
+					if (e < nout && incl - 1u < uint32_t(BLOCK)) {
+						C hi;
+						if (vnb) {
+							const uint32_t bk = __umulhi(e, vmagic);
+							hi = lds_get_bits<C>(img, vbase * 8u + bk * 128u + (e - bk * vcap) * vnb,
+									     vnb);
+						} else {
+							hi = hv[e];
+						}
+						val[incl - 1u] |= C(hi << nb) & E::MASK;
+					}
+				}
+			}
+			wave_sync();
+		}
+		C u[VPL];
+		if constexpr (sizeof(C) == 4) {
+			const uint4 q = *reinterpret_cast<const uint4 *>(&val[lane * VPL]);
+			u[0] = q.x, u[1] = q.y, u[2] = q.z, u[3] = q.w;
+		} else {
+#pragma unroll
+			for (int s = 0; s < VPL; s++)
+				u[s] = val[lane * VPL + s];
+		}
+#pragma unroll
+		for (int s = 0; s < VPL; s++)
+			v[s] = enc == OROCH_BITPCK ? unzz<E>(u[s]) : C((u[s] + origin) & E::MASK);
+	} else if (enc == OROCH_VARINT || enc == OROCH_VARFOR) {
+		// varint.h:141-147
+		for (int i = lane; i < BLOCK; i += WAVE)
+			val[i] = 0;
+		wave_sync();
+		varint_list_decode<C>(img8, doff, len, uint32_t(nv), val, lane);
+#pragma unroll
+		for (int s = 0; s < VPL; s++) {
+			C u = val[lane * VPL + s] & E::MASK;
+			v[s] = enc == OROCH_VARINT ? unzz<E>(u) : C((u + origin) & E::MASK);
+		}
+	}
+}
+
+// ---- walking the blocks of a stream ------------------------------------------------
+//
+// Persistent wavefronts, each walking blocks wave, wave + stride, ...  The
+// stream offsets are fetched two blocks ahead and the block image one block
+// ahead (into registers), so that the two dependent memory latencies of a
+// block (offset, then bytes) overlap with the decoding of earlier blocks.
+//
+// want(blk, img, len) is asked once the image is in LDS: WALK_DECODE decodes the
+// block and hands the values to sink(blk, nv, v), WALK_SKIP goes on to the
+// next block, WALK_STOP ends this wavefront's walk.  All answers are wave-uniform.
+constexpr int WALK_SKIP = 0, WALK_DECODE = 1, WALK_STOP = -1;
+
+template <typename E, typename Want, typename Sink>
+__device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
+					     const uint64_t *__restrict__ offsets, size_t n,
+					     size_t nblocks, Want want, Sink sink)
+{
+	using C = typename E::C;
+	constexpr uint32_t MAXLEN = uint32_t(image_bytes<E>() - 16);
+	constexpr int NCH = int((MAXLEN + 1023) / 1024); // 1 KiB pieces: one uint4 per lane each
+	// image: the block's bytes; vals: one slot per value (list scratch, patches)
+	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
+	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK + FIELDS_PAD];
+	__shared__ __attribute__((aligned(16))) C highs[WAVES_PER_WG][BLOCK];
+	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
+	__shared__ uint4 wt[65];
+	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
+	load_width_table(wt);
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
+	uint32_t *img = image[wave];
+	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+
+	// Vector loads on purpose: a scalar load would be waited for at the next
+	// LDS access (they share a counter), a vector load stays in flight.
+	auto extent = [&](size_t blk, uint64_t &off, uint64_t &end) {
+		off = 0;
+		end = 0;
+		if (blk < nblocks) {
+			const uint64_t *p = offsets + blk + (lane & 1);
+			const uint64_t x = __builtin_nontemporal_load(p);
+			off = x;
+			end = x;
+		}
+	};
+	// Offsets come from the caller's table and may be anything: every block is
+	// confined to [0, offsets[nblocks]), the length of the stream, so a damaged
+	// table yields wrong values but no read outside the stream.
+	const uint64_t limit = uniform(offsets[nblocks]);
+	auto resolve = [&](uint64_t &off, uint64_t end, uint32_t &len) {
+		// lane 0 holds offsets[blk], lane 1 offsets[blk + 1]
+		const uint64_t o = min_u64(read_lane(off, 0), limit) & ~uint64_t(15);
+		const uint64_t e = min_u64(read_lane(end, 1), limit);
+		off = o;
+		const uint32_t eh = uint32_t(e >> 32), oh = uint32_t(o >> 32);
+		const bool forward = eh > oh || (eh == oh && uint32_t(e) >= uint32_t(o));
+		len = forward ? clamp_u64(e - o, MAXLEN) : 0u;
+	};
+	auto fetch = [&](uint64_t off, uint32_t len, uint4 (&im)[NCH]) {
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+			im[c] = make_uint4(0, 0, 0, 0);
+			if (o < len)
+				im[c] = *reinterpret_cast<const uint4 *>(src + off + o);
+		}
+	};
+
+	size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
+	uint64_t off0, off1, off2, end0, end1, end2;
+	uint32_t len0, len1;
+	uint4 im0[NCH], im1[NCH];
+	extent(blk, off0, end0);
+	extent(blk + stride, off1, end1);
+	resolve(off0, end0, len0);
+	fetch(off0, len0, im0);
+	for (; blk < nblocks; blk += stride) {
+		extent(blk + 2 * stride, off2, end2);
+		resolve(off1, end1, len1);
+		fetch(off1, len1, im1);
+
+		const int nv = block_count(n, blk);
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+			if (o < len0 || o == 0)
+				*reinterpret_cast<uint4 *>(img8 + o) = im0[c];
+		}
+		wave_sync();
+		const int w = want(blk, img, len0);
+		if (w == WALK_STOP)
+			break;
+		if (w == WALK_DECODE) {
+			C v[VPL];
+			if (nv == BLOCK)
+				decode_block<E, true>(img, len0, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+			else
+				decode_block<E, false>(img, len0, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+			sink(blk, nv, v);
+		}
+		wave_sync();
+
+		off0 = off1;
+		len0 = len1;
+		off1 = off2;
+		end1 = end2;
+#pragma unroll
+		for (int c = 0; c < NCH; c++)
+			im0[c] = im1[c];
+	}
+}
+
+} // namespace oroch_hip

@@ -13,7 +13,7 @@
 // else (other encodings, mixed widths, bit-packed or long lists, a short last
 // block) goes block by block through decode_block, from the same staged bytes.
 //
-// Included by group.hip after decode_block; 8-, 16- and 32-bit element types.
+// Needs block.hpp; 8-, 16- and 32-bit element types.
 #pragma once
 
 namespace oroch_hip {
@@ -210,11 +210,12 @@ __device__ __forceinline__ uint32_t group_mask(uint64_t ballot)
 
 // Decodes those blocks of the quad staged in qbuf (block g at byte rel[g], rel
 // in lanes 0..4) that qualify for the four-block path and returns them as a
-// bit mask; the caller does the others one by one.
-template <typename E>
+// bit mask; the caller does the others one by one.  The 256 values of block s
+// of the quad go to sink(s, lane, v), lane l holding values 4l .. 4l+3.
+template <typename E, typename Sink>
 __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint32_t qbytes, uint32_t rel,
 						  int lane, typename E::C *slots, uint8_t *ends,
-						  const uint4 *wt, typename E::S *dst, size_t base)
+						  const uint4 *wt, Sink &&sink)
 {
 	using C = typename E::C;
 	static_assert(sizeof(C) == 4, "element types up to 32 bits");
@@ -348,7 +349,7 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 #pragma unroll
 			for (int i = 0; i < VPL; i++)
 				v[i] = enc == OROCH_BITPCK ? unzz<E>(v[i] & E::MASK) : C((v[i] + origin) & E::MASK);
-			store_block<E>(dst, base + size_t(s) * BLOCK, BLOCK, lane, v);
+			sink(s, lane, v);
 		}
 		wave_sync();
 	}
@@ -359,14 +360,17 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 // Persistent wavefronts over quads of blocks; offsets are fetched two quads
 // ahead and the quad's bytes one quad ahead (the first 3 KiB of them, into
 // registers that are free again once the current quad is staged in LDS), so
-// the dependent latencies overlap with decoding.  The kernel is latency-bound
+// the dependent latencies overlap with decoding.  The loop is latency-bound
 // (a chain of LDS round trips per quad): registers and LDS are kept to what
 // five wavefronts per SIMD allow.
-template <typename E>
-__global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_decode_quad(const uint8_t *__restrict__ src,
-								      const uint64_t *__restrict__ offsets,
-								      size_t n, size_t nblocks,
-								      typename E::S *__restrict__ dst)
+//
+// want(first block of the quad) is asked before a quad is decoded: WALK_STOP
+// ends this wavefront's walk.  The values of block blk (nv of them) go to
+// sink(blk, nv, lane, v), lane l holding values 4l .. 4l+3.
+template <typename E, typename Want, typename Sink>
+__device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
+					    const uint64_t *__restrict__ offsets, size_t n, size_t nblocks,
+					    Want want, Sink sink)
 {
 	using C = typename E::C;
 	constexpr uint32_t IMG = uint32_t(image_bytes<E>() - 16); // longest block image
@@ -446,9 +450,14 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 
 		const size_t blk0 = q * QUAD;
 		const size_t base = blk0 * BLOCK;
+		if (want(blk0) == WALK_STOP)
+			break;
 		uint32_t done = 0;
 		if (blk0 + QUAD <= nblocks && base + size_t(QUAD) * BLOCK <= n)
-			done = decode_quad_fast<E>(qbuf, total0, rel0, lane, slots, endss[wave], wt, dst, base);
+			done = decode_quad_fast<E>(qbuf, total0, rel0, lane, slots, endss[wave], wt,
+						   [&](int s, int ln, const C(&v)[VPL]) {
+							   sink(blk0 + size_t(s), BLOCK, ln, v);
+						   });
 		if (done != 15u) {
 			// the others one by one, from the same staged bytes
 			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 					decode_block<E, true>(img, len, nv, lane, val, hv, gp, wt, v);
 				else
 					decode_block<E, false>(img, len, nv, lane, val, hv, gp, wt, v);
-				store_block<E>(dst, base + size_t(b) * BLOCK, nv, lane, v);
+				sink(blk0 + size_t(b), nv, lane, v);
 				wave_sync();
 			}
 		}
@@ -476,6 +485,17 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 		rel0 = rel1;
 		total0 = total1;
 	}
+}
+
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_decode_quad(
+	const uint8_t *__restrict__ src, const uint64_t *__restrict__ offsets, size_t n, size_t nblocks,
+	typename E::S *__restrict__ dst)
+{
+	using C = typename E::C;
+	walk_quads<E>(
+		src, offsets, n, nblocks, [](size_t) { return WALK_DECODE; },
+		[&](size_t blk, int nv, int lane, const C(&v)[VPL]) { store_block<E>(dst, blk * BLOCK, nv, lane, v); });
 }
 
 } // namespace oroch_hip

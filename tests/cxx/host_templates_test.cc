@@ -3,13 +3,16 @@
 // follow the reference's unit tests (tests/unit/bitpck.cc, bitfor.cc,
 // bitpfr.cc, integer_codec.cc, integer_group.cc) so that a reader can put the
 // two side by side; the oracle comparisons go beyond them.
+#include <algorithm>
 #include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <sstream>
 #include <vector>
 
+#include <oroch/integer_array.h>
 #include <oroch/integer_container.h>
 #include <oroch/integer_group.h>
 
@@ -420,6 +423,127 @@ static void test_container()
 	REQUIRE(thrown);
 }
 
+// tests/unit/integer_array.cc: "small integer array" and "large integer array".
+static void test_array_reference_cases()
+{
+	{
+		oroch::integer_array<int32_t> array;
+		REQUIRE(array.find(0) == oroch::not_found);
+		REQUIRE(array.find(1) == oroch::not_found);
+		array.insert(0, 0);
+		REQUIRE(array.at(0) == 0);
+		REQUIRE(array.find(0) == 0);
+		array.insert(0, 1);
+		REQUIRE(array.at(0) == 1);
+		REQUIRE(array.at(1) == 0);
+		REQUIRE(array.find(0) == 1);
+		REQUIRE(array.find(1) == 0);
+	}
+	const size_t n = 100000;
+	oroch::integer_array<int32_t> array;
+	for (size_t i = 0; i < n; i++)
+		array.insert(i, int32_t(i));
+	array.insert(0, -1);
+	REQUIRE(array.size() == n + 1);
+	// every 7th value on its own (one device pass per call), then all in one pass
+	size_t bad = 0;
+	for (size_t i = 0; i < n; i += 7)
+		bad += array.find(int32_t(i)) != i + 1;
+	REQUIRE(bad == 0);
+	std::vector<int32_t> all(n);
+	for (size_t i = 0; i < n; i++)
+		all[i] = int32_t(i);
+	const std::vector<size_t> where = array.find(all);
+	for (size_t i = 0; i < n; i++)
+		bad += where[i] != i + 1;
+	REQUIRE(bad == 0);
+	REQUIRE(array.find(-1) == 0);
+	REQUIRE(array.find(int32_t(n)) == oroch::not_found);
+}
+
+// The array against a std::vector that sees the same operations; the groups
+// against the oracle's block images.
+template <typename T>
+static void test_array()
+{
+	const int dt = oroch::hip::dtype_of<T>();
+	std::vector<T> model;
+	oroch::integer_array<T> array;
+	REQUIRE(array.empty());
+	const size_t counts[] = {3, 253, 256, 1, 700, 2048, 11};
+	for (size_t count : counts) {
+		std::vector<T> piece;
+		while (piece.size() < count) {
+			const std::vector<T> part = make_block<T>(int(rnd() % 8), std::min<size_t>(256, count - piece.size()));
+			piece.insert(piece.end(), part.begin(), part.end());
+		}
+		array.append(piece.begin(), piece.end());
+		model.insert(model.end(), piece.begin(), piece.end());
+	}
+	const size_t spots[] = {model.size(), model.size() - 1, 1000, 256, 255, 0};
+	for (size_t spot : spots) {
+		const T v = T(rnd());
+		array.insert(spot, v);
+		model.insert(model.begin() + spot, v);
+	}
+	REQUIRE(array.size() == model.size() && !array.empty());
+	REQUIRE(array.read(0, model.size()) == model);
+	REQUIRE(array.read(200, 600) == std::vector<T>(model.begin() + 200, model.begin() + 800));
+	// groups: byte for byte what the oracle writes for the same values
+	const size_t ngroups = model.size() / 256;
+	std::vector<uint8_t> want(orc_group_bound(dt, 256) * (ngroups + 1) + 64), image(sizeof(T) * 256 + 64);
+	std::vector<uint64_t> offs(ngroups + 1);
+	orc_blocks_encode(dt, model.data(), ngroups * 256, 256, 16, want.data(), offs.data());
+	size_t differ = 0;
+	for (size_t g = 0; g < ngroups; g++) {
+		uint64_t bytes = 0;
+		oroch::hip::check(oroch_array_image(array.handle(), g, image.data(), image.size(), &bytes), "image");
+		differ += bytes != offs[g + 1] - offs[g] || std::memcmp(image.data(), want.data() + offs[g], bytes) != 0;
+	}
+	REQUIRE(differ == 0);
+	uint64_t bytes = 0;
+	REQUIRE(oroch_array_image(array.handle(), ngroups, image.data(), image.size(), &bytes) == OROCH_E_RANGE);
+	// at / find, one by one and in bulk, groups and tail
+	std::vector<size_t> pos;
+	std::vector<T> needles;
+	for (int i = 0; i < 40; i++) {
+		pos.push_back(size_t(rnd() % model.size()));
+		needles.push_back(i % 4 == 3 ? T(rnd()) : model[pos.back()]);
+	}
+	pos.push_back(model.size() - 1);
+	needles.push_back(model.back());
+	const std::vector<T> got = array.at(pos);
+	const std::vector<size_t> found = array.find(needles);
+	for (size_t i = 0; i < pos.size(); i++) {
+		REQUIRE(got[i] == model[pos[i]]);
+		REQUIRE(array[pos[i]] == model[pos[i]]);
+		const auto it = std::find(model.begin(), model.end(), needles[i]);
+		const size_t expect = it == model.end() ? oroch::not_found : size_t(it - model.begin());
+		REQUIRE(found[i] == expect);
+		REQUIRE(array.find(needles[i]) == expect);
+	}
+	bool thrown = false;
+	try {
+		array.at(model.size());
+	} catch (const std::out_of_range &) {
+		thrown = true;
+	}
+	REQUIRE(thrown);
+	thrown = false;
+	try {
+		array.insert(model.size() + 1, T(0));
+	} catch (const std::out_of_range &) {
+		thrown = true;
+	}
+	REQUIRE(thrown);
+	std::ostringstream os;
+	array.group_info(os);
+	const std::string text = os.str();
+	REQUIRE(size_t(std::count(text.begin(), text.end(), '\n')) == ngroups);
+	array.clear();
+	REQUIRE(array.empty() && array.find(T(1)) == oroch::not_found);
+}
+
 static void test_errors()
 {
 	std::vector<int32_t> v(257, 3);
@@ -457,6 +581,7 @@ static void run_type(const char *name)
 	test_sequences<T>();
 	test_blocks<T>();
 	test_container<T>();
+	test_array<T>();
 	std::printf("%-8s ok so far: %d checks, %d failed\n", name, g_checks, g_failed);
 	std::fflush(stdout);
 }
@@ -471,6 +596,7 @@ int main()
 	test_bitpfr_two_calls();
 	test_group_reference_case();
 	test_errors();
+	test_array_reference_cases();
 	run_type<int8_t>("int8");
 	run_type<uint8_t>("uint8");
 	run_type<int16_t>("int16");
