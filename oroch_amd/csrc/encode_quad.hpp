@@ -29,6 +29,18 @@ __device__ __forceinline__ int row_scan_max(int x)
 	return x;
 }
 
+// The same for unsigned values; with 0 as the identity each step is one
+// max instruction that takes its operand through the lane shift.
+__device__ __forceinline__ uint32_t row_scan_max(uint32_t x)
+{
+	uint32_t y;
+	y = dpp_mov<0x111>(0u, x); x = x > y ? x : y;
+	y = dpp_mov<0x112>(0u, x); x = x > y ? x : y;
+	y = dpp_mov<0x114>(0u, x); x = x > y ? x : y;
+	y = dpp_mov<0x118>(0u, x); x = x > y ? x : y;
+	return x;
+}
+
 // Lane p, p + 64, ... packs word p of a class of blocks (see class_word) from
 // the slots and stores it at its place in the stream.
 template <typename E, int NB>

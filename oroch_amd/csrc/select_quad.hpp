@@ -13,7 +13,7 @@
 
 namespace oroch_hip {
 
-constexpr int HQ_DWORDS = 196;  // per group: 33 bins x 4 copies; 196 puts the groups' tables 4 banks apart
+constexpr int HQ_DWORDS = 196;  // per group: 34 bins x 4 copies; 196 puts the groups' tables 4 banks apart
 constexpr int NO_DWORDS = 64;   // per group: exception counts by width, zero above the widest
 constexpr int PW_ENTRIES = 34;  // per group: per-width candidate parameters
 
@@ -46,6 +46,25 @@ __device__ __forceinline__ int leading_zeros(uint32_t x)
 	int r;
 	asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
 	return r;
+}
+// v_ffbh_i32: how many leading bits of x equal its sign bit, -1 for 0 and -1.
+__device__ __forceinline__ int leading_sign_bits(int32_t x)
+{
+	int r;
+	asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(x));
+	return r;
+}
+// Multiplies of small numbers: the 24-bit multiply runs at full rate, the
+// 32-bit ones at a quarter of it.
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b)
+{
+	return uint32_t(__umul24(a, b));
+}
+// 16 * ceil(count / capacity): bitpck.h:61-71 for count + capacity - 1 < 512,
+// w = {capacity, ., ceil(2^16 / capacity), .}
+__device__ __forceinline__ uint32_t pck_bytes(uint32_t count, const uint4 &w)
+{
+	return (mul24(count + w.x - 1u, w.z) >> 16) << 4;
 }
 
 // The 16 bits of a ballot that belong to this lane's group.
@@ -89,7 +108,8 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	using C = typename E::C;
 	static_assert(sizeof(C) == 4, "element types up to 32 bits");
 	asm volatile("" : "+v"(lane)); // see decode_quad_fast
-	const int g = lane / GROUP, sub = lane % GROUP;
+	static_assert(GROUP == 16, "lane arithmetic below");
+	const int g = int(uint32_t(lane) >> 4), sub = int(uint32_t(lane) & 15u);
 	const uint32_t bA = uint32_t(sub) + 1u, bB = uint32_t(sub) + 17u;
 
 	sel.encoding = OROCH_NORMAL;
@@ -126,25 +146,44 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	// bin 0 is "value zero" and bin c + 1 is bit length 32 - c) and are four
 	// dwords each (one per sub & 3, to spread same-address atomics): delta
 	// count in the low half, zigzag count in the high half.
-	uint32_t *table = hq + g * HQ_DWORDS;
+	//
+	// For a signed type the bit length of zigzag(v) is 33 minus the number of
+	// leading bits of v that equal its sign, which one instruction counts;
+	// it answers -1 for both 0 and -1, and those go to a bin of their own in
+	// front of bin 0.  Nothing below tells them apart: both cost one varint
+	// byte, and a block of nothing else packs at width 1 either way.
+	uint32_t *table = hq + mul24(uint32_t(g), HQ_DWORDS) + 4;
 #pragma unroll
 	for (int k = 0; k < HQ_DWORDS / (GROUP * 4); k++)
-		*reinterpret_cast<uint4 *>(&table[(k * GROUP + sub) * 4]) = make_uint4(0, 0, 0, 0);
+		*reinterpret_cast<uint4 *>(&table[(k * GROUP + sub) * 4 - 4]) = make_uint4(0, 0, 0, 0);
 	uint32_t *nog = no + g * NO_DWORDS;
 	nog[32 + sub] = 0;
 	nog[48 + sub] = 0;
 	wave_sync();
 	uint32_t *mine = table + 4 + (sub & 3);
+	uint32_t *minez = E::sgn ? mine - 4 : mine;
 	// leading-zero counts of the deltas, four to a register (value 4j + r in
-	// byte j of lz[r]; 127 for a zero delta)
-	uint32_t lz[4] = {0, 0, 0, 0};
+	// byte j of lz[r]; 255 for a zero delta)
+	int cds[VPQ];
 #pragma unroll
 	for (int i = 0; i < VPQ; i++) {
 		const int cd = leading_zeros(uint32_t((v[i] - mn) & E::MASK));
-		const int cz = leading_zeros(uint32_t(zz<E>(v[i])));
+		int cz;
+		if constexpr (E::sgn)
+			cz = leading_sign_bits(int32_t(v[i] << (32 - E::W)) >> (32 - E::W));
+		else
+			cz = leading_zeros(uint32_t(v[i]));
 		atomicAdd(&mine[cd * 4], 1u);
-		atomicAdd(&mine[cz * 4], 0x10000u);
-		lz[i & 3] |= (uint32_t(cd) & 0x7fu) << (8 * (i >> 2));
+		atomicAdd(&minez[cz * 4], 0x10000u);
+		cds[i] = cd;
+	}
+	uint32_t lz[4];
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		// low bytes of four counts into one register
+		const uint32_t lo = __builtin_amdgcn_perm(uint32_t(cds[r + 4]), uint32_t(cds[r]), 0x0c0c0400u);
+		const uint32_t hi = __builtin_amdgcn_perm(uint32_t(cds[r + 12]), uint32_t(cds[r + 8]), 0x0c0c0400u);
+		lz[r] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 	}
 	wave_sync();
 	// width b <-> bin 33 - b
@@ -153,14 +192,19 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	const uint4 q0 = *reinterpret_cast<const uint4 *>(&table[0]);
 	const uint32_t sa = qa.x + qa.y + qa.z + qa.w;
 	const uint32_t sb = qb.x + qb.y + qb.z + qb.w;
-	const uint32_t s0 = q0.x + q0.y + q0.z + q0.w;
+	uint32_t s0 = q0.x + q0.y + q0.z + q0.w;
+	if constexpr (E::sgn) {
+		// the zigzag half of the zero count sits one bin lower
+		const uint4 qm = *reinterpret_cast<const uint4 *>(&table[-4]);
+		s0 = (s0 & 0xffffu) + ((qm.x + qm.y + qm.z + qm.w) & 0xffff0000u);
+	}
 	const uint32_t dA = sa & 0xffffu, zA = sa >> 16, dB = sb & 0xffffu, zB = sb >> 16;
 	const uint32_t zero_d = s0 & 0xffffu, zero_z = s0 >> 16;
 	const bool constant = zero_d == uint32_t(BLOCK); // integer_codec.h:255-264, applied at the end
 
 	// the two varint footprints, integer_codec.h:483-489, from the histograms
 	const uint32_t wA = lc.wA, wB = lc.wB;
-	const uint32_t t = row_sum(dA * wA + dB * wB + ((zA * wA + zB * wB) << 16));
+	const uint32_t t = row_sum(mul24(dA, wA) + mul24(dB, wB) + ((mul24(zA, wA) + mul24(zB, wB)) << 16));
 	const uint32_t vfs = (t & 0xffffu) + zero_d, vis = (t >> 16) + zero_z;
 	// widest delta and widest zigzag image
 	const uint32_t nbmax = row_max(dB ? bB : (dA ? bA : 0u));
@@ -217,14 +261,14 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	// ceil((k - b) / 7), i.e. the sum over j >= 0 of nout(b + 7j) (:308-312)
 	const uint32_t valvarA = noutA + nog[bA + 6] + nog[bA + 13] + nog[bA + 20] + nog[bA + 27];
 	const uint32_t basic_meta = 1 + vo;
-	uint4 *pwg = pw + g * PW_ENTRIES;
+	uint4 *pwg = pw + mul24(uint32_t(g), PW_ENTRIES);
 	bool candA, candB;
 	uint32_t estA, estB;
 	{
 		const bool active = bA < nbmax && dA != 0;
 		const uint32_t xmeta = 2 + (noutA < 128u ? 1u : 2u);
 		const uint4 cm = wt[active ? nbmax - bA : 1u];
-		const uint32_t valpck = 16u * __umulhi(noutA + cm.x - 1u, cm.y);
+		const uint32_t valpck = pck_bytes(noutA, cm);
 		const uint32_t venc = valpck < valvarA ? OROCH_BITPCK : OROCH_VARINT;
 		const uint32_t vdata = valpck < valvarA ? valpck : valvarA;
 		const uint32_t indmin = noutA > 128u ? 32u : 16u; // min(pck(nout, 1), 256), nout in 1..255
@@ -242,7 +286,7 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint32_t valvarB = noutB + nog[bB + 6] + nog[bB + 13] + nog[bB + 20] + nog[bB + 27];
 		const uint32_t xmeta = 2 + (noutB < 128u ? 1u : 2u);
 		const uint4 cm = wt[active ? nbmax - bB : 1u];
-		const uint32_t valpck = 16u * __umulhi(noutB + cm.x - 1u, cm.y);
+		const uint32_t valpck = pck_bytes(noutB, cm);
 		const uint32_t venc = valpck < valvarB ? OROCH_BITPCK : OROCH_VARINT;
 		const uint32_t vdata = valpck < valvarB ? valpck : valvarB;
 		const uint32_t indmin = noutB > 128u ? 32u : 16u;
@@ -276,8 +320,8 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint4 par = pwg[tryit ? bL : 1u];
 		const uint32_t fixedL = par.y, noutL = par.z & 0xffffu;
 		// My exceptions at this width, bit i for value i: bit length above bL,
-		// i.e. fewer than 32 - bL leading zeros (a zero delta reads as 127).
-		const uint32_t thr = (32u - bL) * 0x01010101u;
+		// i.e. fewer than 32 - bL leading zeros (a zero delta reads as 255).
+		const uint32_t thr = __builtin_amdgcn_perm(32u - bL, 32u - bL, 0u); // in all four bytes
 		// bit 7 of a byte comes out set iff that byte of lz is >= 32 - bL: not
 		// an exception.  Flags land at bit 8j + r for value 4j + r, then move
 		// together into 16 bits.
@@ -290,22 +334,27 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		// Index gaps, :338-351.  The gap in front of my first exception reaches
 		// back to the last exception of the lanes before me; the gaps between
 		// my own exceptions are runs of zeros inside m.
+		// (positions count from 1 here, 0 = none, so that the scan's identity is 0)
 		const uint32_t hb = 31u - uint32_t(__clz(m | 1u));
-		const int lastpos = m ? sub * VPQ + int(hb) : -1;
-		const int prev0 = dpp_mov<0x111>(-1, row_scan_max(lastpos));
+		const uint32_t lastpos1 = m ? uint32_t(sub * VPQ) + hb + 1u : 0u;
+		uint32_t prev1 = dpp_mov<0x111>(0u, row_scan_max(lastpos1));
+		// Keeps the lane shift an instruction of its own: folded into the
+		// subtraction below (v_subrev_u32 with a DPP operand) the result was
+		// wrong on the device.
+		asm volatile("" : "+v"(prev1));
 		const uint32_t fb = uint32_t(__builtin_ctz(m | 0x10000u));
-		const uint32_t gfirst = m ? uint32_t(sub * VPQ + int(fb) - prev0 - 1) : 0u;
+		const uint32_t gfirst = m ? uint32_t(sub * VPQ) + fb - prev1 : 0u;
 		// zeros strictly between my lowest and highest exception
 		const uint32_t z1 = ~m & ((2u << hb) - 1u) & ~((1u << fb) - 1u) & 0xffffu;
 		const uint32_t z2 = z1 & (z1 >> 1), z4 = z2 & (z2 >> 2), z8 = z4 & (z4 >> 4);
-		const uint32_t inbits = (z1 ? 1u : 0u) + (z2 ? 1u : 0u) + (z4 ? 1u : 0u) + (z8 ? 1u : 0u);
+		const uint32_t inbits = (z1 < 1u ? z1 : 1u) + (z2 < 1u ? z2 : 1u) + (z4 < 1u ? z4 : 1u) + (z8 < 1u ? z8 : 1u);
 		const uint32_t fbits = bitlen(gfirst);
 		uint32_t indnbits = row_max(fbits > inbits ? fbits : inbits); // bit length of the longest gap
 		// 256 positions hold at most one gap of 128 or more
 		uint32_t indvar = noutL + (indnbits == 8u ? 1u : 0u);
 		indnbits = indnbits ? indnbits : 1u;
 		const uint4 ci = wt[indnbits];
-		const uint32_t indpck = 16u * __umulhi(noutL + ci.x - 1u, ci.y);
+		const uint32_t indpck = pck_bytes(noutL, ci);
 		const uint32_t ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
 		const uint32_t idata = indpck < indvar ? indpck : indvar;
 		const uint32_t required = fixedL + idata;
@@ -355,8 +404,10 @@ __device__ __forceinline__ void desc_words(const quad_selection &sel, uint4 &da,
 			sel.ienc | (sel.inbits << 8) | (sel.venc << 16) | (sel.vnbits << 24), 0u);
 }
 
+// (registers capped at what five wavefronts per SIMD allow: the kernel is
+// bound by instruction issue and the fifth wavefront fills stalls of the others)
 template <typename E>
-__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select_quad(const typename E::S *__restrict__ src,
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_select_quad(const typename E::S *__restrict__ src,
 								      size_t n, size_t nblocks,
 								      oroch_block_desc *__restrict__ desc,
 								      uint32_t *__restrict__ sizes)
