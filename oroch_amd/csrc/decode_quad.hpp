@@ -180,7 +180,7 @@ __device__ __forceinline__ void unpack_quad_words(const quad_class &c, const uin
 			const uint2 *q = reinterpret_cast<const uint2 *>(qb + at) + j * 2;
 			const uint2 x = q[0], y = q[1];
 			const uint32_t w[4] = {x.x, x.y, y.x, y.y};
-			unpack_fields<C, NB>(w, slots + (gp - first) * SLOT_STRIDE, int(j));
+			unpack_fields<C, NB>(w, slots + __umul24(gp - first, SLOT_STRIDE), int(j));
 		}
 	}
 }
@@ -225,7 +225,8 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 	// width, ahead of the quad loop and keeps it in registers (over 200 of
 	// them).  An opaque lane number makes it recompute the little it needs.
 	asm volatile("" : "+v"(lane));
-	const int g = lane / GROUP, sub = lane % GROUP;
+	static_assert(GROUP == 16, "lane arithmetic below");
+	const int g = int(uint32_t(lane) >> 4), sub = int(uint32_t(lane) & 15u);
 	const uint32_t r0 = lane_gather(rel, g), r1 = lane_gather(rel, g + 1);
 	const uint32_t len = r1 - r0;
 	const bool inside = r0 + 16u <= qbytes && r1 <= qbytes && r0 < r1;
@@ -242,7 +243,9 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 	// at least 16 of them.
 	const bool is_pfr = m.enc == OROCH_BITPFR;
 	const uint4 iw = wt[m.inb && m.inb <= 32u ? m.inb : 1u], vw = wt[m.vnb && m.vnb <= 32u ? m.vnb : 1u];
-	const uint32_t ilen_pck = 16u * __umulhi(m.nout + iw.x - 1u, iw.y); // bitpck.h:61-71
+	// bitpck.h:61-71 with the 16-bit reciprocal (exact below 512; a count beyond
+	// QUAD_MAX_EXC fails the test further down whatever this gives)
+	const uint32_t ilen_pck = (uint32_t(__umul24(m.nout + iw.x - 1u, iw.z)) >> 16) << 4;
 	const uint32_t scan_rel = list_at + (m.inb ? ilen_pck : 0u);        // where varints start
 	if (is_pfr) {
 		// one exception per lane of the group; a block with more goes the
@@ -266,7 +269,7 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 	if (__ballot(has_exc) != 0) {
 		const uint32_t lb = r0 + list_at;      // index list; a multiple of 8
 		const uint32_t sb = r0 + scan_rel;     // first varint, if any list has them
-		uint8_t *my_ends = ends + g * ENDS;
+		uint8_t *my_ends = ends + __umul24(uint32_t(g), ENDS);
 		if (__ballot(has_exc && (!m.inb || !m.vnb)) != 0) {
 			// every lane looks at four bytes of the window and files the end
 			// position of each varint that ends there under the varint's number
@@ -291,7 +294,7 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 		const bool active = has_exc && e < m.nout;
 		uint32_t gap = 0, hi = 0;
 		if (__ballot(active && m.inb) != 0) {
-			const uint32_t bk = __umulhi(e, iw.y);
+			const uint32_t bk = uint32_t(__umul24(e, iw.z)) >> 16;
 			gap = lds_get_bits32(qbuf, lb * 8u + bk * 128u + (e - bk * iw.x) * m.inb, m.inb ? m.inb : 1u);
 		}
 		if (__ballot(active && !m.inb) != 0) {
@@ -300,7 +303,7 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 			gap = m.inb ? gap : x;
 		}
 		if (__ballot(active && m.vnb) != 0) {
-			const uint32_t bk = __umulhi(e, vw.y);
+			const uint32_t bk = uint32_t(__umul24(e, vw.z)) >> 16;
 			hi = lds_get_bits32(qbuf, vb * 8u + bk * 128u + (e - bk * vw.x) * m.vnb, m.vnb ? m.vnb : 1u);
 		}
 		if (__ballot(active && !m.vnb) != 0) {
@@ -333,7 +336,7 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 		wave_sync();
 		// lanes with nothing to patch here OR zero into a spare slot
 		const bool now = hit && in_half;
-		atomicOr(&slots[now ? uint32_t(g & 1) * SLOT_STRIDE + pos : uint32_t(2 * SLOT_STRIDE - 1)],
+		atomicOr(&slots[now ? __umul24(uint32_t(g & 1), SLOT_STRIDE) + pos : uint32_t(2 * SLOT_STRIDE - 1)],
 			 now ? patch : C(0));
 		wave_sync();
 		// every lane picks up four values of each block; origin and encoding

@@ -61,7 +61,7 @@ __device__ __forceinline__ void pack_quad_words(const quad_class &c, const typen
 		const uint32_t at = lane_gather(data_at, int(gp * GROUP));
 		if (p < P) {
 			uint32_t w[4];
-			pack_fields<C, NB, true>(slots + gp * SLOT_STRIDE, int(j), w);
+			pack_fields<C, NB, true>(slots + __umul24(gp, SLOT_STRIDE), int(j), w);
 			*reinterpret_cast<uint4 *>(out + at + j * 16u) = make_uint4(w[0], w[1], w[2], w[3]);
 		}
 	}
@@ -95,7 +95,8 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 	using C = typename E::C;
 	static_assert(sizeof(C) == 4, "element types up to 32 bits");
 	asm volatile("" : "+v"(lane)); // see decode_quad_fast
-	const int g = lane / GROUP, sub = lane % GROUP;
+	static_assert(GROUP == 16, "lane arithmetic below");
+	const int g = int(uint32_t(lane) >> 4), sub = int(uint32_t(lane) & 15u);
 
 	const C origin = da.x;
 	const uint32_t dataspace = da.z, size = da.w;
@@ -120,7 +121,7 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 
 	// deltas (or zigzag images) of all values into the slots, in full: the
 	// packer cuts them to the width, the exception lists need the rest
-	C *mine = slots + g * SLOT_STRIDE;
+	C *mine = slots + __umul24(uint32_t(g), SLOT_STRIDE); // (full-rate multiply)
 	const bool has_exc = ok && enc == OROCH_BITPFR;
 	const bool zig = E::sgn && enc == OROCH_BITPCK;
 	const C org = enc == OROCH_BITPCK ? C(0) : origin;
@@ -145,10 +146,15 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 	// which of my values are exceptions
 	uint32_t m = 0;
 	if (__ballot(has_exc) != 0) {
+		// u >= 2^nb exactly when u + (2^32 - 2^nb) carries; the carries are
+		// shifted into m from the top value down (an add with carry-out and
+		// an add with carry-in per value)
+		const uint32_t lift = 0u - (1u << (nb & 31u));
 #pragma unroll
-		for (int i = 0; i < VPQ; i++) {
-			const uint32_t hi = uint32_t(u[i] >> (nb & 31u));
-			m |= (hi ? 1u : 0u) << i;
+		for (int i = VPQ - 1; i >= 0; i--) {
+			uint32_t sum;
+			const uint32_t carry = __builtin_add_overflow(uint32_t(u[i]), lift, &sum) ? 1u : 0u;
+			m = m + m + carry;
 		}
 		m = has_exc && nb < 32u ? m : 0u;
 	}
@@ -207,25 +213,25 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 		const int upto = row_scan_max(last);
 		const int prev0 = dpp_mov<0x111>(-1, upto); // last exception in lower lanes
 		const uint4 iw = wt[inb ? inb : 1u], vw = wt[vnb ? vnb : 1u];
-		// first pass over my exceptions: how many list bytes they take
-		uint32_t ib = 0, vb = 0;
-		{
+		// first pass over my exceptions: how many list bytes they take.  A
+		// gap takes two varint bytes from 128 on, which only the gap in front
+		// of a lane's first exception can reach.
+		const uint32_t gfirst = uint32_t(sub * VPQ + int(__builtin_ctz(m | 0x10000u)) - prev0 - 1);
+		const uint32_t ib = cnt + (m && gfirst >= 128u ? 1u : 0u);
+		uint32_t vb = 0;
+		if (__ballot(has_exc && venc != OROCH_BITPCK) != 0) {
 			uint32_t mm = m;
-			int prev = prev0;
 			while (__ballot(mm != 0) != 0) {
 				if (mm) {
 					const int pos = sub * VPQ + int(__builtin_ctz(mm));
-					const uint32_t gap = uint32_t(pos - prev - 1);
-					prev = pos;
-					const C hi = mine[pos] >> nb;
-					ib += gap >= 128u ? 2u : 1u;
-					vb += vsp(hi);
+					vb += vsp(C(mine[pos] >> nb));
 					mm &= mm - 1u;
 				}
 			}
 		}
 		const uint32_t isum = row_scan_sum(ib), vsum = row_scan_sum(vb);
-		const uint32_t ilen = ienc == OROCH_BITPCK ? 16u * __umulhi(nout + iw.x - 1u, iw.y)
+		// (bitpck.h:61-71 with the 16-bit reciprocal: nout + capacity - 1 < 512)
+		const uint32_t ilen = ienc == OROCH_BITPCK ? (uint32_t(__umul24(nout + iw.x - 1u, iw.z)) >> 16) << 4
 							    : lane_gather(isum, g * GROUP + GROUP - 1);
 		uint32_t io = isum - ib, vo = ilen + vsum - vb, r = before;
 		uint32_t *tail32 = reinterpret_cast<uint32_t *>(tail);
@@ -239,7 +245,7 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 					prev = pos;
 					const C hi = mine[pos] >> nb;
 					if (ienc == OROCH_BITPCK) {
-						const uint32_t bk = __umulhi(r, iw.y);
+						const uint32_t bk = uint32_t(__umul24(r, iw.z)) >> 16;
 						lds_or_bits(tail32, bk * 128u + (r - bk * iw.x) * inb, gap);
 					} else {
 						tail[io++] = uint8_t((gap & 0x7fu) | (gap >= 128u ? 0x80u : 0u));
@@ -247,7 +253,7 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 							tail[io++] = uint8_t(gap >> 7);
 					}
 					if (venc == OROCH_BITPCK) {
-						const uint32_t bk = __umulhi(r, vw.y);
+						const uint32_t bk = uint32_t(__umul24(r, vw.z)) >> 16;
 						lds_or_bits(tail32, ilen * 8u + bk * 128u + (r - bk * vw.x) * vnb, hi);
 					} else {
 						vo = put_varint(tail, vo, uint64_t(hi));
@@ -293,9 +299,9 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 		const size_t blk0 = q * QUAD;
 		uint32_t done = 0;
 		if (blk0 + QUAD <= nblocks && (blk0 + QUAD) * BLOCK <= n) {
-			const size_t blk = blk0 + size_t(lane / GROUP);
+			const size_t blk = blk0 + size_t(uint32_t(lane) >> 4);
 			C v[VPQ];
-			load16<E>(src + blk * BLOCK + size_t(lane % GROUP) * VPQ, v);
+			load16<E>(src + blk * BLOCK + size_t(uint32_t(lane) & 15u) * VPQ, v);
 			const uint4 *dq = reinterpret_cast<const uint4 *>(desc + blk);
 			const uint4 da = dq[0], db = dq[1];
 			const uint64_t off = offsets[blk];

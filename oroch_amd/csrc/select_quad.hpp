@@ -83,7 +83,7 @@ struct quad_lane_consts
 
 __device__ __forceinline__ quad_lane_consts make_quad_lane_consts(const uint4 *wt, int lane)
 {
-	const uint32_t sub = uint32_t(lane % GROUP);
+	const uint32_t sub = uint32_t(lane) & 15u;
 	quad_lane_consts c;
 	c.wA = vsp_bits(sub + 1u);
 	c.wB = vsp_bits(sub + 17u);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 	for (size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave; q < nquads; q += stride) {
 		const size_t blk0 = q * QUAD;
 		if (blk0 + QUAD <= nblocks && (blk0 + QUAD) * BLOCK <= n) {
-			const int g = lane / GROUP, sub = lane % GROUP;
+			const int g = int(uint32_t(lane) >> 4), sub = int(uint32_t(lane) & 15u);
 			const size_t blk = blk0 + size_t(g);
 			C v[VPQ];
 			load16<E>(src + blk * BLOCK + size_t(sub) * VPQ, v);
