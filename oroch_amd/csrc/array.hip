@@ -131,8 +131,146 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 		});
 }
 
-// Value number index[q] of the array for each of m queries: one wavefront per
-// query decodes the block that holds it.  A position at or beyond n yields 0.
+// ---- random access -------------------------------------------------------------------------
+
+// Up to 64 bits at bit position `bit` of the packed 16-byte words that start
+// at byte `at` of a block image (bitpck.h:203-225: a field never leaves its
+// word); 0 where the word would reach beyond the image.
+__device__ __forceinline__ uint64_t image_bits(const uint8_t *img, uint32_t len, uint32_t at, uint32_t bit,
+					       uint32_t nbits)
+{
+	const uint32_t w = at + (bit >> 7) * 16u;
+	if (w + 16u > len)
+		return 0;
+	const uint64_t *q = reinterpret_cast<const uint64_t *>(img + w);
+	const uint32_t sh = bit & 127u;
+	uint64_t x;
+	if (sh < 64u) {
+		x = q[0] >> sh;
+		if (sh && sh + nbits > 64u)
+			x |= q[1] << (64u - sh);
+	} else {
+		x = q[1] >> (sh - 64u);
+	}
+	return nbits >= 64u ? x : x & ((uint64_t(1) << nbits) - 1u);
+}
+
+// varint.h:85-115 at byte p of a block image in global memory; advances p.
+__device__ __forceinline__ uint64_t image_varint(const uint8_t *img, uint32_t len, uint32_t &p)
+{
+	uint64_t value = 0;
+	uint32_t shift = 0;
+	for (;;) {
+		const uint32_t byte = p < len ? img[p] : 0u;
+		p++;
+		if (shift < 64)
+			value |= uint64_t(byte & 0x7fu) << shift;
+		shift += 7;
+		if ((byte & 0x80u) == 0 || shift > 70)
+			break;
+	}
+	return value;
+}
+
+// One value of a block straight from its image in global memory, without
+// decoding the block: what a fetch is for the bit-packed encodings
+// (bitpck.h:203-225, 258-266), the constant and the raw ones.  A patched
+// block (integer_codec.h:583-609) adds a walk over its exception positions,
+// taken here for up to AT_WALK exceptions.  Returns false where the block has
+// to be decoded instead (varints as values, long exception lists, metadata
+// the encoder does not write).
+constexpr uint32_t AT_WALK = 32;
+
+template <typename E>
+__device__ __forceinline__ bool value_direct(const uint8_t *img, uint32_t len, uint32_t nv, uint32_t pos,
+					     const uint4 *wt, typename E::C &out)
+{
+	using C = typename E::C;
+	out = 0;
+	if (len < 16u)
+		return true; // no image: decodes to zeros as well
+	const uint4 hw = *reinterpret_cast<const uint4 *>(img);
+	const uint64_t h0 = (uint64_t(hw.y) << 32) | hw.x, h1 = (uint64_t(hw.w) << 32) | hw.z;
+	const uint32_t enc = uint32_t(h0) & 0xffu;
+	uint32_t p = 1;
+	if (enc == OROCH_NORMAL) {
+		// normal.h:51-58
+		const uint32_t at = 8u + pos * uint32_t(E::BYTES);
+		if (at + uint32_t(E::BYTES) <= len)
+			out = C(*reinterpret_cast<const typename E::S *>(img + at)) & E::MASK;
+		return true;
+	}
+	if (enc != OROCH_NAUGHT && enc != OROCH_BITPCK && enc != OROCH_BITFOR && enc != OROCH_BITPFR)
+		return false;
+	C origin = 0;
+	if (enc != OROCH_BITPCK)
+		origin = unzz<E>(C(hdr_varint(h0, h1, p)) & E::MASK);
+	if (enc == OROCH_NAUGHT) {
+		out = origin; // naught.h:42-47
+		return true;
+	}
+	const uint32_t nb = hdr_byte(h0, h1, p++);
+	if (nb < 1u || nb > uint32_t(E::W))
+		return false;
+	uint32_t nout = 0, inb = 0, vnb = 0;
+	if (enc == OROCH_BITPFR) {
+		nout = uint32_t(hdr_varint(h0, h1, p));
+		inb = hdr_byte(h0, h1, p++);
+		vnb = hdr_byte(h0, h1, p++);
+		if (nout > AT_WALK || nout > nv || vnb > uint32_t(E::W) || inb > 64u)
+			return false;
+	}
+	const uint32_t doff = (p + 7u) & ~7u; // integer_group.h:70-72
+	const uint4 w = wt[nb];
+	const uint32_t word = __umulhi(pos, w.y); // pos / capacity
+	C u = C(image_bits(img, len, doff, word * 128u + (pos - word * w.x) * nb, nb)) & E::MASK;
+	if (nout) {
+		// the position list, offset.h:62-67: each entry is the distance from
+		// the entry before it, less one
+		const uint32_t ibase = doff + pck_space(wt, nv, nb);
+		const uint4 iw = wt[inb ? inb : 1u];
+		uint32_t ip = ibase, next = 0, found = nout;
+		for (uint32_t e = 0; e < nout; e++) {
+			uint32_t gap;
+			if (inb) {
+				const uint32_t bk = __umulhi(e, iw.y);
+				gap = uint32_t(image_bits(img, len, ibase, bk * 128u + (e - bk * iw.x) * inb, inb));
+			} else {
+				gap = uint32_t(image_varint(img, len, ip));
+			}
+			next += gap + 1u;
+			if (next - 1u == pos)
+				found = e;
+			// (a list of varints is walked to its end: the values start there)
+			if (inb && next > pos)
+				break;
+		}
+		if (found < nout) {
+			const uint32_t vbase = inb ? ibase + pck_space(wt, nout, inb) : ip;
+			C hi;
+			if (vnb) {
+				const uint4 vw = wt[vnb];
+				const uint32_t bk = __umulhi(found, vw.y);
+				hi = C(image_bits(img, len, vbase, bk * 128u + (found - bk * vw.x) * vnb, vnb));
+			} else {
+				uint32_t vp = vbase;
+				for (uint32_t e = 0; e < found; e++)
+					(void) image_varint(img, len, vp);
+				hi = C(image_varint(img, len, vp));
+			}
+			if (nb < uint32_t(E::W))
+				u |= C(hi << nb) & E::MASK;
+		}
+	}
+	out = enc == OROCH_BITPCK ? unzz<E>(u) : C((u + origin) & E::MASK);
+	return true;
+}
+
+// Value number index[q] of the array for each of m queries.  Every lane takes
+// one query and reads its value straight from the block image where the
+// encoding allows; the queries that are left are then served one at a time by
+// the whole wavefront, which decodes the block (array_integer_group<T>::
+// operator[], integer_array.h:64-69).  A position at or beyond n yields 0.
 template <typename E>
 __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_at(const uint8_t *__restrict__ src,
 							     const uint64_t *__restrict__ offsets, size_t n,
@@ -153,46 +291,58 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_at(const uint8_t *__rest
 	uint32_t *img = image[wave];
 	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
 	const uint64_t limit = uniform(offsets[nblocks]);
-	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
-	for (size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave; q < m; q += stride) {
-		const uint64_t at = uniform(index[q]);
-		const uint32_t ah = uint32_t(at >> 32), nh = uint32_t(uint64_t(n) >> 32);
-		const bool inside = ah < nh || (ah == nh && uint32_t(at) < uint32_t(n));
-		if (!inside) {
-			if (lane == 0)
-				dst[q] = S(0);
-			continue;
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG * WAVE;
+	for (size_t q0 = (size_t(blockIdx.x) * WAVES_PER_WG + wave) * WAVE; q0 < m; q0 += stride) {
+		const size_t q = q0 + size_t(lane);
+		// my query: the block's extent, confined to the stream as in walk_blocks
+		uint64_t o = 0;
+		uint32_t len = 0, pos = 0, nv = 0;
+		bool need = false;
+		if (q < m) {
+			const uint64_t at = index[q];
+			C x = 0;
+			if (at < uint64_t(n)) {
+				const size_t blk = size_t(at / BLOCK);
+				pos = uint32_t(at % BLOCK);
+				const uint64_t left = uint64_t(n) - uint64_t(blk) * BLOCK;
+				nv = left < uint64_t(BLOCK) ? uint32_t(left) : uint32_t(BLOCK);
+				const uint64_t b = offsets[blk], e = offsets[blk + 1];
+				o = (b < limit ? b : limit) & ~uint64_t(15);
+				const uint64_t end = e < limit ? e : limit;
+				len = end > o ? uint32_t(end - o < uint64_t(MAXLEN) ? end - o : uint64_t(MAXLEN)) : 0u;
+				need = !value_direct<E>(src + o, len, nv, pos, wt, x);
+			}
+			if (!need)
+				dst[q] = S(x);
 		}
-		const size_t blk = size_t(at / BLOCK);
-		const uint32_t pos = uint32_t(at % BLOCK);
-		const int nv = block_count(n, blk);
-		// the block's extent, confined to the stream as in walk_blocks
-		const uint64_t o = min_u64(uniform(offsets[blk]), limit) & ~uint64_t(15);
-		const uint64_t e = min_u64(uniform(offsets[blk + 1]), limit);
-		const uint32_t eh = uint32_t(e >> 32), oh = uint32_t(o >> 32);
-		const bool forward = eh > oh || (eh == oh && uint32_t(e) >= uint32_t(o));
-		const uint32_t len = forward ? clamp_u64(e - o, MAXLEN) : 0u;
+		// the queries that need their block decoded, one after the other
+		for (uint64_t todo = __ballot(need); todo; todo &= todo - 1) {
+			const int l = int(__builtin_ctzll(todo));
+			const uint64_t bo = read_lane(o, l);
+			const uint32_t blen = read_lane(len, l), bpos = read_lane(pos, l);
+			const int bnv = int(read_lane(nv, l));
 #pragma unroll
-		for (int c = 0; c < NCH; c++) {
-			const uint32_t b = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
-			uint4 x = make_uint4(0, 0, 0, 0);
-			if (b < len)
-				x = *reinterpret_cast<const uint4 *>(src + o + b);
-			if (b < len || b == 0)
-				*reinterpret_cast<uint4 *>(img8 + b) = x;
+			for (int c = 0; c < NCH; c++) {
+				const uint32_t b = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+				uint4 x = make_uint4(0, 0, 0, 0);
+				if (b < blen)
+					x = *reinterpret_cast<const uint4 *>(src + bo + b);
+				if (b < blen || b == 0)
+					*reinterpret_cast<uint4 *>(img8 + b) = x;
+			}
+			wave_sync();
+			C v[VPL];
+			if (bnv == BLOCK)
+				decode_block<E, true>(img, blen, bnv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+			else
+				decode_block<E, false>(img, blen, bnv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+			if (uint32_t(lane) == bpos / VPL) {
+				const uint32_t s = bpos % VPL;
+				const C x = s == 0 ? v[0] : s == 1 ? v[1] : s == 2 ? v[2] : v[3];
+				dst[q0 + size_t(l)] = S(x);
+			}
+			wave_sync();
 		}
-		wave_sync();
-		C v[VPL];
-		if (nv == BLOCK)
-			decode_block<E, true>(img, len, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
-		else
-			decode_block<E, false>(img, len, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
-		if (uint32_t(lane) == pos / VPL) {
-			const uint32_t s = pos % VPL;
-			const C x = s == 0 ? v[0] : s == 1 ? v[1] : s == 2 ? v[2] : v[3];
-			dst[q] = S(x);
-		}
-		wave_sync();
 	}
 }
 
@@ -261,7 +411,7 @@ extern "C" int oroch_group_at(int dtype, const void *src, const uint64_t *offset
 	const size_t nb = (n + BLOCK - 1) / BLOCK;
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
-		hipLaunchKernelGGL(k_at<E>, dim3(walk_grid(m)), dim3(WAVE * WAVES_PER_WG), 0, st,
+		hipLaunchKernelGGL(k_at<E>, dim3(walk_grid((m + WAVE - 1) / WAVE)), dim3(WAVE * WAVES_PER_WG), 0, st,
 				   static_cast<const uint8_t *>(src), offsets, n, nb, index, m,
 				   static_cast<typename E::S *>(dst));
 		return int(hipGetLastError());

@@ -86,6 +86,10 @@ def test_find_and_at_over_block_images(hip, dt, monkeypatch):
         got = host(hip.group_at(stream, offs, a.size, dt, pos)).view(dt)
         exp = np.where(pos < a.size, a[np.minimum(pos, a.size - 1)], 0).astype(dt)
         assert np.array_equal(got, exp), (dt, nblocks, last)
+        # every position once: all encodings, exceptions and their neighbours, both
+        # the direct reads and the blocks that have to be decoded
+        every = host(hip.group_at(stream, offs, a.size, dt, np.arange(a.size))).view(dt)
+        assert np.array_equal(every, a), (dt, nblocks, last, np.flatnonzero(every != a)[:8])
 
 
 @pytest.mark.parametrize("one_block", ["0", "1"])
