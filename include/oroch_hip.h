@@ -194,6 +194,12 @@ int oroch_group_stats(int dtype, const void *src, size_t n, oroch_block_stats *s
 int oroch_group_select(int dtype, const void *src, size_t n, oroch_block_desc *desc,
 		       void *stream);
 
+/*
+ * Arrays of values (src of select / stats / encode, dst of decode) are device
+ * memory aligned to 4 bytes, 8 for 64-bit elements: any allocation, and any slice
+ * of one that starts at a multiple of four elements.  OROCH_E_ARGUMENT otherwise.
+ */
+
 /* Worst-case bytes of the batch stream for n values; workspace bytes needed. */
 size_t oroch_group_bound(int dtype, size_t n);
 size_t oroch_group_workspace(int dtype, size_t n);

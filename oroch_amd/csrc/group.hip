@@ -1181,10 +1181,19 @@ extern "C" size_t oroch_group_workspace(int dtype, size_t n)
 	return carve_ws(nullptr, n).bytes;
 }
 
+// The kernels move values with multi-dword accesses: 4-byte alignment at least
+// (8 for 64-bit elements), which every allocation and every slice at a multiple
+// of four elements has.
+static bool values_aligned(int dtype, const void *p)
+{
+	const uintptr_t need = (dtype >> 1) == 3 ? 8u : 4u;
+	return (reinterpret_cast<uintptr_t>(p) & (need - 1u)) == 0;
+}
+
 extern "C" int oroch_group_select(int dtype, const void *src, size_t n, oroch_block_desc *desc,
 				  void *stream)
 {
-	if (n && (!src || !desc))
+	if ((n && (!src || !desc)) || !values_aligned(dtype, src))
 		return OROCH_E_ARGUMENT;
 	const size_t nb = nblocks_of(n);
 	if (nb == 0)
@@ -1202,7 +1211,7 @@ extern "C" int oroch_group_select(int dtype, const void *src, size_t n, oroch_bl
 extern "C" int oroch_group_stats(int dtype, const void *src, size_t n, oroch_block_stats *stats,
 				 void *stream)
 {
-	if (n && (!src || !stats))
+	if ((n && (!src || !stats)) || !values_aligned(dtype, src))
 		return OROCH_E_ARGUMENT;
 	const size_t nb = nblocks_of(n);
 	if (nb == 0)
@@ -1228,7 +1237,8 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 		return OROCH_E_DTYPE;
 	if (!offsets || (n && (!src || !dst || !workspace)))
 		return OROCH_E_ARGUMENT;
-	if ((reinterpret_cast<uintptr_t>(dst) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 15u))
+	if ((reinterpret_cast<uintptr_t>(dst) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 15u) ||
+	    !values_aligned(dtype, src))
 		return OROCH_E_ARGUMENT;
 	if (dst_capacity < oroch_group_bound(dtype, n) || workspace_bytes < oroch_group_workspace(dtype, n))
 		return OROCH_E_CAPACITY;
@@ -1339,7 +1349,7 @@ extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *of
 		return OROCH_E_DTYPE;
 	if (n && (!src || !dst || !offsets))
 		return OROCH_E_ARGUMENT;
-	if (reinterpret_cast<uintptr_t>(src) & 15u)
+	if ((reinterpret_cast<uintptr_t>(src) & 15u) || !values_aligned(dtype, dst))
 		return OROCH_E_ARGUMENT;
 	const size_t nb = nblocks_of(n);
 	if (nb == 0)

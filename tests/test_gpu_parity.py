@@ -485,3 +485,34 @@ def test_varint_sequences(hip, oracle, golden, dt):
     if dt.kind == "u" and W >= 16:
         for v, b in known.items():
             assert host(hip.varint_encode(dev(np.array([v], dt)))).tolist() == b
+
+
+@pytest.mark.parametrize("dt", [np.int8, np.int16, np.int32, np.int64])
+def test_value_arrays_at_odd_offsets(hip, oracle, dt):
+    """Values that start 4 bytes (8 for 64-bit elements) into an allocation: the
+    least alignment the entry points take; less than that is refused."""
+    import torch
+
+    dt = np.dtype(dt)
+    step = max(4, dt.itemsize) // dt.itemsize
+    rng = np.random.default_rng(808 + dt.itemsize)
+    a = np.concatenate([dg.fuzz_block(rng, dt, 256) for _ in range(21)] + [dg.fuzz_block(rng, dt, 99)])
+    whole = dev(np.concatenate([np.zeros(step, dt), a]))
+    x = whole[step:]
+    assert x.data_ptr() % 16 != 0
+    exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+    stream, offs = hip.group_encode(x)
+    assert np.array_equal(host(offs).astype(np.uint64), exp_offs)
+    assert np.array_equal(host(stream), exp)
+    out = torch.zeros(a.size + step, dtype=x.dtype, device="cuda")
+    code = hip.dtype_code(dt)
+    rc = hip.lib.oroch_group_decode(code, stream.data_ptr(), offs.data_ptr(), a.size,
+                                    out[step:].data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(host(out[step:]).view(dt), a)
+    assert not host(out[:step]).any()
+    if dt.itemsize < 4:
+        y = whole[1:]
+        desc = torch.empty(32 * 32, dtype=torch.uint8, device="cuda")
+        assert hip.lib.oroch_group_select(code, y.data_ptr(), 256, desc.data_ptr(), None) == -5  # OROCH_E_ARGUMENT
