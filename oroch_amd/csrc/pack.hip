@@ -515,6 +515,10 @@ extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_
 		return OROCH_E_NBITS; // bitpfr.h:65: the mask is (1 << nbits) - 1, nbits < bits(T)
 	if (!nexc || !workspace || (exc_capacity && (!indices || !values)))
 		return OROCH_E_ARGUMENT;
+	// the exception passes read the values sixteen at a time: 4-byte alignment
+	// at least, 8 for 64-bit elements
+	if (reinterpret_cast<uintptr_t>(src) & ((dtype >> 1) == 3 ? 7u : 3u))
+		return OROCH_E_ARGUMENT;
 	if (workspace_bytes < oroch_bitpfr_workspace(n))
 		return OROCH_E_CAPACITY;
 	hipStream_t st = static_cast<hipStream_t>(stream);
