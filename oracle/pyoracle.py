@@ -87,6 +87,7 @@ class Lib:
         else:
             f("group_decode", sz, [C.c_int, vp, sz, sz, vp])
             f("bench_blocks", None, [C.c_int, vp, sz, sz, C.c_int, vp])
+            f("array_script", sz, [C.c_int, vp, sz, vp, vp, sz, vp, vp, sz, vp, vp, sz])
 
     def _f(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -233,6 +234,24 @@ class Lib:
         out = np.zeros(5, np.float64)
         self._bench_blocks(dtype_code(a.dtype), _ptr(a), a.size, block, threads, _ptr(out))
         return out
+
+
+def ref_array_script(values, ins_pos, ins_val, needles):
+    """The reference's integer_array: insert values one by one at the end, then
+    ins_val[k] at ins_pos[k], then find() every needle.  Returns (positions as
+    uint64, text of group_info(), which insertions the reference accepted)."""
+    values = np.ascontiguousarray(values)
+    dt = values.dtype
+    ins_pos = np.ascontiguousarray(ins_pos, np.uint64)
+    ins_val = np.ascontiguousarray(ins_val, dt)
+    needles = np.ascontiguousarray(needles, dt)
+    found = np.zeros(needles.size, np.uint64)
+    taken = np.zeros(ins_pos.size, np.uint8)
+    info = np.zeros(64 * (values.size // 256 + ins_pos.size + 2) + 64, np.uint8)
+    k = ref._array_script(dtype_code(dt), _ptr(values), values.size, _ptr(ins_pos), _ptr(ins_val),
+                          ins_pos.size, _ptr(taken), _ptr(needles), needles.size, _ptr(found), _ptr(info),
+                          info.size)
+    return found, bytes(info[:k]).decode("latin-1"), taken.astype(bool)
 
 
 def raw64(v, dt):

@@ -10,6 +10,7 @@
 #include <oroch/bitfor.h>
 #include <oroch/bitpck.h>
 #include <oroch/bitpfr.h>
+#include <oroch/integer_array.h>
 #include <oroch/integer_codec.h>
 #include <oroch/integer_group.h>
 #include <oroch/integer_stats.h>
@@ -19,6 +20,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <sstream>
 #include <thread>
 #include <vector>
 
@@ -298,6 +300,40 @@ struct ref
 
 } // namespace
 
+// The reference's integer_array (integer_array.h:150-259) through a script:
+// values[0..n) are inserted at the end one by one, then nops insertions at
+// the given positions follow, then every needle is looked up with find().
+// found[j] receives the position (or not_found); info receives the text of
+// group_info() (one line of metadata per full group) and its length is returned.
+// taken[k] tells whether insertion k went through: the reference's range check
+// (integer_array.h:221) throws std::out_of_range when the position within its
+// group exceeds the length of the tail, also for positions inside the array.
+template <typename T>
+static size_t array_script(const T *values, size_t n, const uint64_t *ins_pos, const T *ins_val,
+			   size_t nops, uint8_t *taken, const T *needles, size_t m, uint64_t *found,
+			   char *info, size_t info_capacity)
+{
+	oroch::integer_array<T> array;
+	for (size_t i = 0; i < n; i++)
+		array.insert(i, values[i]);
+	for (size_t k = 0; k < nops; k++) {
+		taken[k] = 1;
+		try {
+			array.insert(size_t(ins_pos[k]), ins_val[k]);
+		} catch (const std::out_of_range &) {
+			taken[k] = 0;
+		}
+	}
+	for (size_t j = 0; j < m; j++)
+		found[j] = uint64_t(array.find(needles[j]));
+	std::ostringstream os;
+	array.group_info(os);
+	const std::string text = os.str();
+	const size_t len = text.size() < info_capacity ? text.size() : info_capacity;
+	std::memcpy(info, text.data(), len);
+	return len;
+}
+
 #define DISPATCH(dtype, expr)                                                                      \
 	switch (dtype) {                                                                           \
 	case 0: { using T = int8_t; return expr; }                                                 \
@@ -390,6 +426,13 @@ size_t ref_blocks_encode(int dtype, const void *src, size_t n, size_t block, siz
 			 uint8_t *dst, uint64_t *offsets)
 {
 	DISPATCH(dtype, ref<T>::blocks_encode((const T *) src, n, block, align, dst, offsets));
+}
+size_t ref_array_script(int dtype, const void *values, size_t n, const uint64_t *ins_pos,
+			const void *ins_val, size_t nops, uint8_t *taken, const void *needles,
+			size_t m, uint64_t *found, char *info, size_t info_capacity)
+{
+	DISPATCH(dtype, array_script<T>((const T *) values, n, ins_pos, (const T *) ins_val, nops, taken,
+					(const T *) needles, m, found, info, info_capacity));
 }
 void ref_bench_blocks(int dtype, const void *src, size_t n, size_t block, int threads, double *out)
 {
