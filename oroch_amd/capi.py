@@ -512,9 +512,12 @@ class IntegerArray:
         _check(lib.oroch_array_create(self.code, C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib.oroch_array_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib.oroch_array_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown: the library may be gone already
+            pass
 
     def __len__(self):
         return lib.oroch_array_size(self._h)

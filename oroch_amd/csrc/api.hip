@@ -212,8 +212,11 @@ int oroch_hip::staged_copy(void *dst, const void *src, size_t bytes, bool to_dev
 	void *const *pin = g_staging.pin;
 	hipEvent_t ev[2];
 	for (int i = 0; i < 2; i++) {
-		if ((rc = int(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming))))
+		if ((rc = int(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)))) {
+			if (i)
+				(void) hipEventDestroy(ev[0]);
 			return rc;
+		}
 	}
 	size_t done = 0;
 	int k = 0;

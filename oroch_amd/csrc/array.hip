@@ -609,18 +609,27 @@ extern "C" int oroch_array_clear(oroch_array *a)
 	return 0;
 }
 
+// (host allocations of the tail must not throw through the C boundary)
 extern "C" int oroch_array_append(oroch_array *a, const void *src, size_t n)
 {
 	if (!a || (n && !src))
 		return OROCH_E_ARGUMENT;
-	return append_any(a, src, n, true);
+	try {
+		return append_any(a, src, n, true);
+	} catch (const std::bad_alloc &) {
+		return int(hipErrorOutOfMemory);
+	}
 }
 
 extern "C" int oroch_array_append_host(oroch_array *a, const void *src_host, size_t n)
 {
 	if (!a || (n && !src_host))
 		return OROCH_E_ARGUMENT;
-	return append_any(a, src_host, n, false);
+	try {
+		return append_any(a, src_host, n, false);
+	} catch (const std::bad_alloc &) {
+		return int(hipErrorOutOfMemory);
+	}
 }
 
 extern "C" int oroch_array_view(const oroch_array *a, const void **stream, const uint64_t **offsets,
@@ -766,7 +775,7 @@ extern "C" int oroch_array_read(oroch_array *a, uint64_t first, uint64_t count, 
 // value up by one: the blocks from the insertion point on are decoded, shifted
 // on the device and encoded again; the value pushed out of the last block
 // becomes the first of the tail.
-extern "C" int oroch_array_insert(oroch_array *a, uint64_t index, uint64_t value)
+static int insert_value(oroch_array *a, uint64_t index, uint64_t value)
 {
 	if (!a)
 		return OROCH_E_ARGUMENT;
@@ -813,4 +822,13 @@ extern "C" int oroch_array_insert(oroch_array *a, uint64_t index, uint64_t value
 	}
 	a->tail.insert(a->tail.begin(), last, last + w);
 	return flush_tail(a);
+}
+
+extern "C" int oroch_array_insert(oroch_array *a, uint64_t index, uint64_t value)
+{
+	try {
+		return insert_value(a, index, value);
+	} catch (const std::bad_alloc &) {
+		return int(hipErrorOutOfMemory);
+	}
 }
