@@ -135,8 +135,7 @@ int oroch_bitpck_fetch(int dtype, int vcodec, const void *src, size_t n, uint64_
  * (v - origin) >> nbits into values[] (both uint64_t on the device, room for
  * `exc_capacity` entries each).  *nexc (device) receives the number of
  * exceptions found even when it exceeds exc_capacity (nothing is written past
- * the capacity).  workspace: oroch_bitpfr_workspace(n) bytes.  src: aligned
- * to 4 bytes, 8 for 64-bit elements.
+ * the capacity).  workspace: oroch_bitpfr_workspace(n) bytes.
  */
 size_t oroch_bitpfr_workspace(size_t n);
 int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits,

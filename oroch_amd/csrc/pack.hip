@@ -27,7 +27,9 @@ struct pack_geom
 	uint32_t k0[2], k1[2];  // first / last value overlapping qword 0 / 1 of a block
 };
 
-static pack_geom make_geom(unsigned nbits)
+// whole_words: tiles of a multiple of 64 values, so that a tile owns whole
+// words of a one-bit-per-value map
+static pack_geom make_geom(unsigned nbits, bool whole_words = false)
 {
 	pack_geom g;
 	g.nbits = nbits;
@@ -35,6 +37,14 @@ static pack_geom make_geom(unsigned nbits)
 	g.magic = uint32_t(((uint64_t(1) << 32) + g.cap - 1) / g.cap);
 	uint32_t tb = PK_TILE_VALUES / g.cap;
 	g.tile_blocks = tb > PK_MAX_BLOCKS ? PK_MAX_BLOCKS : (tb ? tb : 1);
+	if (whole_words) {
+		// 64 blocks hold a multiple of 64 values whatever the capacity; a
+		// capacity of 128 does with 32 of them
+		if (g.tile_blocks >= 64)
+			g.tile_blocks &= ~63u;
+		else
+			g.tile_blocks = g.cap % 64 == 0 ? g.tile_blocks : 64;
+	}
 	for (int w = 0; w < 2; w++) {
 		g.k0[w] = (64u * w) / nbits;
 		uint32_t last = (64u * w + 63u) / nbits;
@@ -60,10 +70,12 @@ __device__ __forceinline__ typename E::C value_decode(typename E::C u, typename 
 		return (u + origin) & E::MASK;
 }
 
-template <typename E, int VC>
+// FLAGS: also writes the map of exceptions (bitpfr.h:75-85), bit v of the map
+// set when value v does not fit nbits once the origin is taken off.
+template <typename E, int VC, bool FLAGS = false>
 __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, size_t n,
 						       size_t nblk, pack_geom g, typename E::C origin,
-						       uint64_t *dst)
+						       uint64_t *dst, uint64_t *map = nullptr)
 {
 	using C = typename E::C;
 	using S = typename E::S;
@@ -76,8 +88,17 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, s
 		const size_t v0 = b0 * g.cap;
 		const uint32_t slots = tb * g.cap;
 		const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
-		for (uint32_t i = threadIdx.x; i < slots; i += PK_THREADS)
-			stage[i] = i < nvals ? S(value_encode<E, VC>(C(src[v0 + i]), origin) & low) : S(0);
+		for (uint32_t i = threadIdx.x; i < slots; i += PK_THREADS) {
+			const C u = i < nvals ? value_encode<E, VC>(C(src[v0 + i]), origin) : C(0);
+			stage[i] = S(u & low);
+			if constexpr (FLAGS) {
+				// the wavefront's 64 consecutive values make one word of the map
+				// (v0 and the tile length are multiples of 64)
+				const uint64_t word = __ballot((u >> g.nbits) != 0);
+				if ((i & (WAVE - 1)) == 0)
+					map[(v0 + i) / WAVE] = word;
+			}
+		}
 		__syncthreads();
 		for (uint32_t q = threadIdx.x; q < 2 * tb; q += PK_THREADS) {
 			const uint32_t blk = q >> 1, w = q & 1;
@@ -161,41 +182,21 @@ constexpr int XT_VPT = 16;
 constexpr int XT_TILE = XT_THREADS * XT_VPT;
 constexpr uint64_t XT_NONE = ~uint64_t(0);
 
-// Bit s set when value base + s does not fit nbits after the origin is taken
-// off (bitpfr.h:75-85).  Sixteen consecutive values per thread, one to four
-// 16-byte loads.
-template <typename E>
-__device__ __forceinline__ uint32_t exc_flags(const typename E::S *src, size_t n, size_t base,
-					      typename E::C origin, uint32_t nbits)
+// The 16 bits of the exception map for values base .. base + 15 (base a
+// multiple of 16).
+__device__ __forceinline__ uint32_t exc_flags(const uint64_t *map, size_t base)
 {
-	using C = typename E::C;
-	C u[XT_VPT];
-	if (base + XT_VPT <= n) {
-		load16<E>(src + base, u);
-	} else {
-#pragma unroll
-		for (int s = 0; s < XT_VPT; s++)
-			u[s] = base + s < n ? C(src[base + s]) : origin;
-	}
-	uint32_t flags = 0;
-#pragma unroll
-	for (int s = 0; s < XT_VPT; s++) {
-		const C hi = C((u[s] - origin) & E::MASK) >> nbits; // nbits < W for bitpfr (bitpfr.h:65)
-		flags |= (hi ? 1u : 0u) << s;
-	}
-	return flags;
+	return uint32_t(map[base / 64] >> (base % 64)) & 0xffffu;
 }
 
 // Pass 1: per tile of 4096 values, the number of exceptions and the position
 // of the last one.
-template <typename E>
-__global__ __launch_bounds__(XT_THREADS) void k_exc_count(const typename E::S *src, size_t n,
-							    typename E::C origin, uint32_t nbits,
-							    uint32_t *counts, uint64_t *last)
+__global__ __launch_bounds__(XT_THREADS) void k_exc_count(const uint64_t *map, uint32_t *counts,
+							    uint64_t *last)
 {
 	__shared__ uint32_t wave_cnt[XT_THREADS / WAVE], wave_last[XT_THREADS / WAVE];
 	const size_t tile_base = size_t(blockIdx.x) * XT_TILE;
-	const uint32_t flags = exc_flags<E>(src, n, tile_base + size_t(threadIdx.x) * XT_VPT, origin, nbits);
+	const uint32_t flags = exc_flags(map, tile_base + size_t(threadIdx.x) * XT_VPT);
 	const uint32_t cnt = wave_sum(uint32_t(__popc(flags)));
 	// highest position in the tile with an exception, plus one; 0 = none
 	const uint32_t lp = wave_max(flags ? threadIdx.x * XT_VPT + (31u - uint32_t(__clz(flags))) + 1u : 0u);
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(XT_THREADS) void k_exc_count(const typename E::S *s
 
 // Pass 2: emit (gap, high part) per exception at its global rank.
 template <typename E>
-__global__ __launch_bounds__(XT_THREADS) void k_exc_emit(const typename E::S *src, size_t n,
+__global__ __launch_bounds__(XT_THREADS) void k_exc_emit(const typename E::S *src, const uint64_t *map,
 							   typename E::C origin, uint32_t nbits,
 							   const uint32_t *counts, const uint64_t *last,
 							   const uint64_t *rank_base, uint64_t *indices,
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(XT_THREADS) void k_exc_emit(const typename E::S *sr
 
 	const size_t tile_base = tile * XT_TILE;
 	const size_t base = tile_base + size_t(threadIdx.x) * XT_VPT;
-	uint32_t flags = exc_flags<E>(src, n, base, origin, nbits);
+	uint32_t flags = exc_flags(map, base);
 	const uint32_t cnt = uint32_t(__popc(flags));
 	const uint32_t incl_cnt = wave_scan_sum(cnt, lane);
 	// last exception at or below this thread, as tile position + 1 (0 = none)
@@ -393,6 +394,8 @@ struct pfr_ws
 	uint64_t *rank_base;  // ntiles + 1
 	uint64_t *tile_sums;
 	uint64_t *total;
+	uint64_t *map;        // one bit per value, whole tiles of XT_TILE
+	size_t map_bytes;
 	size_t bytes;
 };
 
@@ -419,6 +422,11 @@ static pfr_ws carve_pfr(void *ws, size_t n)
 	off = up256(off + (stiles + 1) * sizeof(uint64_t));
 	w.total = reinterpret_cast<uint64_t *>(p + off);
 	off = up256(off + 256);
+	w.map = reinterpret_cast<uint64_t *>(p + off);
+	// the packer writes whole words up to the end of the last packed block
+	// (at most 127 values beyond n), the passes read whole tiles
+	w.map_bytes = (ntiles + 1) * (XT_TILE / 8);
+	off = up256(off + w.map_bytes);
 	w.bytes = off;
 	return w;
 }
@@ -515,32 +523,40 @@ extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_
 		return OROCH_E_NBITS; // bitpfr.h:65: the mask is (1 << nbits) - 1, nbits < bits(T)
 	if (!nexc || !workspace || (exc_capacity && (!indices || !values)))
 		return OROCH_E_ARGUMENT;
-	// the exception passes read the values sixteen at a time: 4-byte alignment
-	// at least, 8 for 64-bit elements
-	if (reinterpret_cast<uintptr_t>(src) & ((dtype >> 1) == 3 ? 7u : 3u))
-		return OROCH_E_ARGUMENT;
 	if (workspace_bytes < oroch_bitpfr_workspace(n))
 		return OROCH_E_CAPACITY;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	if (n == 0)
 		return int(hipMemsetAsync(nexc, 0, sizeof(uint64_t), st));
-	int rc = do_pack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
-	if (rc)
-		return rc;
+	if (!src || !dst || (reinterpret_cast<uintptr_t>(dst) & 7u))
+		return OROCH_E_ARGUMENT;
 	pfr_ws w = carve_pfr(workspace, n);
 	const size_t ntiles = (n + XT_TILE - 1) / XT_TILE;
+	// One pass over the values packs them and maps the exceptions; the list
+	// passes then work from the map and read only the exceptions themselves.
+	int rc = int(hipMemsetAsync(w.map, 0, w.map_bytes, st));
+	if (rc)
+		return rc;
+	const pack_geom g = make_geom(nbits, true);
+	const size_t nblk = (n + g.cap - 1) / g.cap;
+	const size_t ptiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		using C = typename E::C;
 		const typename E::S *s = static_cast<const typename E::S *>(src);
 		const C org = C(origin & uint64_t(E::MASK));
+		{
+			profile_scope ps(OROCH_K_PACK, st);
+			hipLaunchKernelGGL((k_pack<E, VC_ORIGIN, true>), dim3(pack_grid(ptiles)), dim3(PK_THREADS), 0,
+					   st, s, n, nblk, g, org, static_cast<uint64_t *>(dst), w.map);
+		}
 		profile_scope ps(OROCH_K_EXCEPT, st);
-		hipLaunchKernelGGL(k_exc_count<E>, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, s, n, org,
-				   nbits, w.counts, w.last);
+		hipLaunchKernelGGL(k_exc_count, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, w.map, w.counts,
+				   w.last);
 		int r = launch_scan<uint32_t, 0>(w.counts, ntiles, w.tile_sums, w.total, w.rank_base, st);
 		if (r)
 			return r;
-		hipLaunchKernelGGL(k_exc_emit<E>, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, s, n, org,
+		hipLaunchKernelGGL(k_exc_emit<E>, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, s, w.map, org,
 				   nbits, w.counts, w.last, w.rank_base, indices, values, exc_capacity);
 		hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, st, nexc, w.rank_base + ntiles);
 		return int(hipGetLastError());
