@@ -70,6 +70,40 @@ __device__ __forceinline__ typename E::C value_decode(typename E::C u, typename 
 		return (u + origin) & E::MASK;
 }
 
+// The values of one 16-byte load, and back (raw bit patterns, zero-extended).
+template <typename E>
+__device__ __forceinline__ void split16(const uint4 &x, typename E::C (&v)[16 / E::BYTES])
+{
+	const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+	if constexpr (E::BYTES == 8) {
+		v[0] = (uint64_t(d[1]) << 32) | d[0];
+		v[1] = (uint64_t(d[3]) << 32) | d[2];
+	} else {
+		constexpr int PER = 4 / E::BYTES; // values per dword
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+#pragma unroll
+			for (int k = 0; k < PER; k++)
+				v[i * PER + k] = (d[i] >> (8 * E::BYTES * k)) & uint32_t(E::MASK);
+	}
+}
+template <typename E>
+__device__ __forceinline__ void join16(const typename E::C (&v)[16 / E::BYTES], uint4 *to)
+{
+	uint32_t d[4] = {0, 0, 0, 0};
+	if constexpr (E::BYTES == 8) {
+		d[0] = uint32_t(v[0]), d[1] = uint32_t(v[0] >> 32), d[2] = uint32_t(v[1]), d[3] = uint32_t(v[1] >> 32);
+	} else {
+		constexpr int PER = 4 / E::BYTES;
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+#pragma unroll
+			for (int k = 0; k < PER; k++)
+				d[i] |= uint32_t(v[i * PER + k]) << (8 * E::BYTES * k);
+	}
+	*to = make_uint4(d[0], d[1], d[2], d[3]);
+}
+
 // FLAGS: also writes the map of exceptions (bitpfr.h:75-85), bit v of the map
 // set when value v does not fit nbits once the origin is taken off.
 template <typename E, int VC, bool FLAGS = false>
@@ -79,27 +113,73 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, s
 {
 	using C = typename E::C;
 	using S = typename E::S;
-	__shared__ S stage[PK_TILE_VALUES];
+	constexpr int PK_VEC = 16 / E::BYTES; // values per 16-byte load
+	__shared__ __attribute__((aligned(16))) S stage[PK_TILE_VALUES];
+	__shared__ uint32_t bits[FLAGS ? PK_TILE_VALUES / 32 : 1];
 	const C low = g.nbits >= uint32_t(E::W) ? E::MASK : C((C(1) << (g.nbits % E::W)) - 1);
 	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
+	// (tiles start at multiples of 64 values: 16-byte loads are aligned when src is)
+	const bool wide_ok = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (g.tile_blocks * g.cap) % 64 == 0;
 	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		if constexpr (FLAGS) {
+			if (threadIdx.x < PK_TILE_VALUES / 32)
+				bits[threadIdx.x] = 0;
+			__syncthreads();
+		}
 		const size_t b0 = tile * g.tile_blocks;
 		const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
 		const size_t v0 = b0 * g.cap;
 		const uint32_t slots = tb * g.cap;
 		const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
-		for (uint32_t i = threadIdx.x; i < slots; i += PK_THREADS) {
-			const C u = i < nvals ? value_encode<E, VC>(C(src[v0 + i]), origin) : C(0);
-			stage[i] = S(u & low);
-			if constexpr (FLAGS) {
-				// the wavefront's 64 consecutive values make one word of the map
-				// (v0 and the tile length are multiples of 64)
-				const uint64_t word = __ballot((u >> g.nbits) != 0);
-				if ((i & (WAVE - 1)) == 0)
-					map[(v0 + i) / WAVE] = word;
+		if (nvals == slots && slots % PK_VEC == 0 && wide_ok) {
+			// a full tile: 16 bytes per lane and load, all loads of the tile in
+			// flight before the first is used
+			constexpr int ROUNDS = PK_TILE_VALUES / (PK_THREADS * PK_VEC);
+			const uint4 *from = reinterpret_cast<const uint4 *>(src + v0);
+			const uint32_t nvec = slots / PK_VEC;
+			uint4 x[ROUNDS];
+#pragma unroll
+			for (int r = 0; r < ROUNDS; r++) {
+				const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
+				x[r] = j < nvec ? from[j] : make_uint4(0, 0, 0, 0);
+			}
+#pragma unroll
+			for (int r = 0; r < ROUNDS; r++) {
+				const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
+				C raw[PK_VEC];
+				split16<E>(x[r], raw);
+				uint32_t nib = 0;
+#pragma unroll
+				for (int k = 0; k < PK_VEC; k++) {
+					const C u = value_encode<E, VC>(raw[k], origin);
+					raw[k] = u & low;
+					if constexpr (FLAGS)
+						nib |= ((u >> g.nbits) != 0 ? 1u : 0u) << k;
+				}
+				if (j < nvec) {
+					join16<E>(raw, reinterpret_cast<uint4 *>(stage) + j);
+					if constexpr (FLAGS) {
+						if (nib)
+							atomicOr(&bits[(j * PK_VEC) / 32], nib << ((j * PK_VEC) % 32));
+					}
+				}
+			}
+		} else {
+			for (uint32_t i = threadIdx.x; i < slots; i += PK_THREADS) {
+				const C u = i < nvals ? value_encode<E, VC>(C(src[v0 + i]), origin) : C(0);
+				stage[i] = S(u & low);
+				if constexpr (FLAGS) {
+					if ((u >> g.nbits) != 0)
+						atomicOr(&bits[i / 32], 1u << (i % 32));
+				}
 			}
 		}
 		__syncthreads();
+		if constexpr (FLAGS) {
+			// the tile's words of the map (v0 and the tile length are multiples of 64)
+			if (threadIdx.x < (slots + 63) / 64)
+				map[v0 / 64 + threadIdx.x] = (uint64_t(bits[2 * threadIdx.x + 1]) << 32) | bits[2 * threadIdx.x];
+		}
 		for (uint32_t q = threadIdx.x; q < 2 * tb; q += PK_THREADS) {
 			const uint32_t blk = q >> 1, w = q & 1;
 			const S *vals = stage + blk * g.cap;
@@ -345,7 +425,7 @@ static int do_pack(int dtype, const void *src, size_t n, uint64_t origin, unsign
 		return 0;
 	if (!src || !dst || (reinterpret_cast<uintptr_t>(dst) & 7u))
 		return OROCH_E_ARGUMENT;
-	const pack_geom g = make_geom(nbits);
+	const pack_geom g = make_geom(nbits, true);
 	const size_t nblk = (n + g.cap - 1) / g.cap;
 	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
 	hipStream_t st = static_cast<hipStream_t>(stream);
