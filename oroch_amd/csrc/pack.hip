@@ -202,8 +202,11 @@ __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t 
 {
 	using C = typename E::C;
 	using S = typename E::S;
+	constexpr int PK_VEC = 16 / E::BYTES; // values per 16-byte store
 	__shared__ __attribute__((aligned(16))) uint32_t stage[PK_MAX_BLOCKS * 4 + 4];
 	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
+	// (tiles start at multiples of 64 values: 16-byte stores are aligned when dst is)
+	const bool wide_ok = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0 && (g.tile_blocks * g.cap) % 64 == 0;
 	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 		const size_t b0 = tile * g.tile_blocks;
 		const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
@@ -213,11 +216,31 @@ __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t 
 		for (uint32_t i = threadIdx.x; i < tb; i += PK_THREADS)
 			reinterpret_cast<uint4 *>(stage)[i] = src[b0 + i];
 		__syncthreads();
-		for (uint32_t i = threadIdx.x; i < nvals; i += PK_THREADS) {
-			const uint32_t blk = __umulhi(i, g.magic);
-			const uint32_t k = i - blk * g.cap;
-			const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
-			dst[v0 + i] = S(value_decode<E, VC>(u, origin));
+		if (nvals == slots && slots % PK_VEC == 0 && wide_ok) {
+			// a full tile: every lane makes 16 bytes of consecutive values per store
+			uint4 *to = reinterpret_cast<uint4 *>(dst + v0);
+			for (uint32_t j = threadIdx.x; j < slots / PK_VEC; j += PK_THREADS) {
+				uint32_t blk = __umulhi(j * PK_VEC, g.magic);
+				uint32_t k = j * PK_VEC - blk * g.cap;
+				C v[PK_VEC];
+#pragma unroll
+				for (int t = 0; t < PK_VEC; t++) {
+					const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+					v[t] = value_decode<E, VC>(u, origin) & E::MASK;
+					if (++k == g.cap) {
+						k = 0;
+						blk++;
+					}
+				}
+				join16<E>(v, to + j);
+			}
+		} else {
+			for (uint32_t i = threadIdx.x; i < nvals; i += PK_THREADS) {
+				const uint32_t blk = __umulhi(i, g.magic);
+				const uint32_t k = i - blk * g.cap;
+				const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+				dst[v0 + i] = S(value_decode<E, VC>(u, origin));
+			}
 		}
 		__syncthreads();
 	}
@@ -452,7 +475,7 @@ static int do_unpack(int dtype, const void *src, size_t n, uint64_t origin, unsi
 		return 0;
 	if (!src || !dst || (reinterpret_cast<uintptr_t>(src) & 15u))
 		return OROCH_E_ARGUMENT;
-	const pack_geom g = make_geom(nbits);
+	const pack_geom g = make_geom(nbits, true);
 	const size_t nblk = (n + g.cap - 1) / g.cap;
 	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
 	hipStream_t st = static_cast<hipStream_t>(stream);
