@@ -181,6 +181,7 @@ __global__ __launch_bounds__(VI_THREADS) void k_varint_take(const uint8_t *src, 
 	using C = typename E::C;
 	__shared__ uint32_t lds[VI_THREADS / WAVE];
 	__shared__ __attribute__((aligned(16))) uint8_t buf[VI_HALO + VI_TILE];
+	__shared__ C out[VI_TILE]; // at most one value per byte
 	const size_t tile_at = size_t(blockIdx.x) * VI_TILE;
 	uint4 w;
 	uint32_t flags = end_flags(src, nbytes, tile_at + size_t(threadIdx.x) * 16, w);
@@ -193,23 +194,28 @@ __global__ __launch_bounds__(VI_THREADS) void k_varint_take(const uint8_t *src, 
 		*reinterpret_cast<uint4 *>(buf) = h;
 	}
 	uint32_t total;
-	uint64_t rank = tile_rank[blockIdx.x] + wg_scan_excl(uint32_t(__popc(flags)), lds, &total);
+	uint32_t r = wg_scan_excl(uint32_t(__popc(flags)), lds, &total);
 	// (wg_scan_excl has synchronised the workgroup: buf is complete)
+	// The tile's values are put together in LDS, in order, and leave in
+	// consecutive stores.
 	while (flags) {
 		const uint32_t p = VI_HALO + threadIdx.x * 16u + uint32_t(__builtin_ctz(flags));
 		flags &= flags - 1u;
-		if (rank < n) {
-			// from the end byte back to the value's first byte, high group first
-			uint64_t acc = buf[p];
-			for (int k = 1; k < varint_max_bytes<E>(); k++) {
-				const uint32_t b = buf[p - k];
-				if (!(b & 0x80u))
-					break;
-				acc = (acc << 7) | (b & 0x7fu);
-			}
-			dst[rank] = typename E::S(unzz<E>(C(acc) & E::MASK));
+		// from the end byte back to the value's first byte, high group first
+		uint64_t acc = buf[p];
+		for (int k = 1; k < varint_max_bytes<E>(); k++) {
+			const uint32_t b = buf[p - k];
+			if (!(b & 0x80u))
+				break;
+			acc = (acc << 7) | (b & 0x7fu);
 		}
-		rank++;
+		out[r++] = unzz<E>(C(acc) & E::MASK);
+	}
+	__syncthreads();
+	const uint64_t rank0 = tile_rank[blockIdx.x];
+	for (uint32_t i = threadIdx.x; i < total; i += VI_THREADS) {
+		if (rank0 + i < n)
+			dst[rank0 + i] = typename E::S(out[i]);
 	}
 }
 
