@@ -72,19 +72,40 @@ __device__ __forceinline__ bool found_below(const unsigned long long *result, si
 template <typename E>
 __device__ __forceinline__ void report_hits(size_t blk, int nv, int lane, const typename E::C (&v)[VPL],
 					    const uint64_t *__restrict__ needles, size_t m,
-					    unsigned long long *result)
+					    typename E::C first, unsigned long long *result)
 {
 	using C = typename E::C;
-	for (size_t j = 0; j < m; j++) {
-		const C x = C(uniform(needles[j])) & E::MASK;
+	if (m == 1) {
+		// the one needle was read when the kernel started
 		int hit = -1;
 #pragma unroll
 		for (int s = VPL - 1; s >= 0; s--)
-			if (v[s] == x && lane * VPL + s < nv)
+			if (v[s] == first && lane * VPL + s < nv)
 				hit = s;
 		if (hit >= 0)
-			atomicMin(&result[j],
-				  (unsigned long long) (uint64_t(blk) * BLOCK + uint64_t(lane * VPL + hit)));
+			atomicMin(&result[0], (unsigned long long) (uint64_t(blk) * BLOCK + uint64_t(lane * VPL + hit)));
+		return;
+	}
+	// 64 needles per load, one per lane, handed round by lane reads
+	for (size_t j0 = 0; j0 < m; j0 += WAVE) {
+		const size_t left = m - j0;
+		const int here = left < size_t(WAVE) ? int(left) : WAVE;
+		const C mine = lane < here ? C(needles[j0 + size_t(lane)]) & E::MASK : C(0);
+		for (int jj = 0; jj < here; jj++) {
+			const C x = read_lane(mine, jj);
+			// four compares per needle; the rest only where some lane has a match
+			const bool any = v[0] == x || v[1] == x || v[2] == x || v[3] == x;
+			if (__ballot(any) == 0)
+				continue;
+			int hit = -1;
+#pragma unroll
+			for (int s = VPL - 1; s >= 0; s--)
+				if (v[s] == x && lane * VPL + s < nv)
+					hit = s;
+			if (hit >= 0)
+				atomicMin(&result[j0 + size_t(jj)],
+					  (unsigned long long) (uint64_t(blk) * BLOCK + uint64_t(lane * VPL + hit)));
+		}
 	}
 }
 
@@ -111,7 +132,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_find(const uint8_t *__re
 				return WALK_STOP;
 			return may_hold<E>(img, first) ? WALK_DECODE : WALK_SKIP;
 		},
-		[&](size_t blk, int nv, const C(&v)[VPL]) { report_hits<E>(blk, nv, lane, v, needles, m, result); });
+		[&](size_t blk, int nv, const C(&v)[VPL]) { report_hits<E>(blk, nv, lane, v, needles, m, first, result); });
 }
 
 // The same on the four-blocks-per-wavefront decoder (element types up to 32
@@ -123,11 +144,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 	const uint64_t *__restrict__ needles, size_t m, unsigned long long *result)
 {
 	using C = typename E::C;
+	const C first = C(uniform(needles[0])) & E::MASK;
 	walk_quads<E>(
 		src, offsets, n, nblocks,
 		[&](size_t blk) { return m == 1 && found_below(result, blk) ? WALK_STOP : WALK_DECODE; },
 		[&](size_t blk, int nv, int lane, const C(&v)[VPL]) {
-			report_hits<E>(blk, nv, lane, v, needles, m, result);
+			report_hits<E>(blk, nv, lane, v, needles, m, first, result);
 		});
 }
 
