@@ -230,3 +230,43 @@ def test_find_and_at_at_scale(hip):
     pos = torch.randint(0, n, (100000,), device="cuda")
     got = hip.group_at(stream, offs, n, np.int32, host(pos))
     assert torch.equal(got, x[pos])
+
+
+@pytest.mark.parametrize("dt", [np.uint8, np.int16, np.int32, np.uint64])
+def test_find_and_at_on_damaged_streams(hip, dt):
+    """Searching and random access read files and network buffers too: damaged
+    offsets or block bytes may give wrong answers, never a read outside the
+    stream (which would show up here as a GPU fault)."""
+    import torch
+
+    dt = np.dtype(dt)
+    rng = np.random.default_rng(61 + dt.itemsize)
+    a = mixed_blocks(rng, dt, 64, 0)
+    n = a.size
+    stream, offs = hip.group_encode(dev(a))
+    total = int(offs[-1])
+    needles = some_needles(rng, a, dt, 8)
+    pos = np.arange(n)
+    o = host(offs).astype(np.uint64)
+    bad = o.copy()
+    bad[3], bad[4] = bad[4], bad[3]
+    bad[10] = np.uint64(total + 4096)
+    bad[17] += np.uint64(5)
+    bad[30] = np.uint64(2 ** 63 + 12345)
+    bad[40] = np.uint64(0)
+    bad_offs = torch.from_numpy(bad.astype(np.int64)).cuda()
+    got = host(hip.group_at(stream, bad_offs, n, dt, pos)).view(dt)
+    ok_blocks = [b for b in range(64) if all(bad[b + d] == o[b + d] for d in (0, 1))]
+    for b in ok_blocks[:8] + ok_blocks[-8:]:
+        assert np.array_equal(got[b * 256:(b + 1) * 256], a[b * 256:(b + 1) * 256]), b
+    hip.group_find(stream, bad_offs, n, dt, needles)
+    hip.group_find(stream, bad_offs, n, dt, needles[:1])
+    for trial in range(3):
+        s = host(stream).copy()
+        hits = rng.integers(0, s.size, size=600)
+        s[hits] ^= rng.integers(1, 256, size=600).astype(np.uint8)
+        ds = torch.from_numpy(s).cuda()
+        hip.group_at(ds, offs, n, dt, pos)
+        hip.group_find(ds, offs, n, dt, needles)
+        hip.group_find(ds, offs, n, dt, needles[:1])
+    torch.cuda.synchronize()
