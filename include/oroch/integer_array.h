@@ -131,6 +131,22 @@ public:
 		return values;
 	}
 
+	// The array as one byte string (the serialised container of
+	// integer_container.h: full groups as they are, the tail as a short last
+	// block) and back.
+	std::vector<byte_t> save() const
+	{
+		std::vector<byte_t> bytes(oroch_array_save_bound(array_));
+		uint64_t total = 0;
+		hip::check(oroch_array_save(array_, bytes.data(), bytes.size(), &total), "integer_array::save");
+		bytes.resize(size_t(total));
+		return bytes;
+	}
+	void load(const std::vector<byte_t> &bytes)
+	{
+		hip::check(oroch_array_load(array_, bytes.data(), bytes.size()), "integer_array::load");
+	}
+
 	// integer_array.h:247-252: one line of metadata per group.
 	void group_info(std::ostream &ostream) const
 	{

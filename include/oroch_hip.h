@@ -386,6 +386,15 @@ int oroch_array_at(oroch_array *array, const uint64_t *index_host, size_t m, voi
 /* Values [first, first + count) into dst_host; OROCH_E_RANGE beyond size. */
 int oroch_array_read(oroch_array *array, uint64_t first, uint64_t count, void *dst_host);
 /*
+ * The array as a serialised container (above) in host memory and back: the
+ * full groups are the container's blocks as they are, the tail its short last
+ * block.  oroch_array_load replaces the content of an array of the same dtype
+ * (OROCH_E_DTYPE otherwise; OROCH_E_ARGUMENT for bytes that are no container).
+ */
+size_t oroch_array_save_bound(const oroch_array *array);
+int oroch_array_save(const oroch_array *array, void *dst_host, size_t capacity, uint64_t *total_host);
+int oroch_array_load(oroch_array *array, const void *src_host, size_t bytes);
+/*
  * Copies the image of one group (what integer_group<T>::encode(aligned = true)
  * writes for its 256 values, zero padded to a multiple of 16) to dst_host;
  * *bytes receives its length, also when capacity is too small

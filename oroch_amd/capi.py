@@ -103,6 +103,9 @@ def _load():
         "oroch_array_at": (i, [vp, vp, sz, vp]),
         "oroch_array_read": (i, [vp, u64, u64, vp]),
         "oroch_array_image": (i, [vp, u64, vp, sz, vp]),
+        "oroch_array_save_bound": (sz, [vp]),
+        "oroch_array_save": (i, [vp, vp, sz, vp]),
+        "oroch_array_load": (i, [vp, vp, sz]),
         "oroch_array_view": (i, [vp, vp, vp, vp, vp, vp, vp]),
         "oroch_hip_profile_start": (i, [i]),
         "oroch_hip_profile_stop": (i, [vp, vp]),
@@ -564,6 +567,17 @@ class IntegerArray:
         out = np.empty(count, self.dtype)
         _check(lib.oroch_array_read(self._h, first, count, out.ctypes.data))
         return out
+
+    def save(self):
+        """The array as a serialised container (numpy uint8)."""
+        out = np.empty(lib.oroch_array_save_bound(self._h), np.uint8)
+        total = C.c_uint64(0)
+        _check(lib.oroch_array_save(self._h, out.ctypes.data, out.size, C.byref(total)))
+        return out[:total.value].copy()
+
+    def load(self, container):
+        c = np.ascontiguousarray(container, np.uint8)
+        _check(lib.oroch_array_load(self._h, c.ctypes.data, c.size))
 
     def view(self):
         """(stream, offsets, tail): the encoded groups as CUDA tensors that alias the

@@ -526,16 +526,8 @@ extern "C" int oroch_bitpfr_patch_host(int dtype, void *dst_host, size_t n, uint
 
 // ---- serialised container ------------------------------------------------------------
 
-namespace {
-
-const uint8_t CONTAINER_MAGIC[8] = {'O', 'R', 'O', 'C', 'H', 'B', 'K', '1'};
-
-size_t container_stream_offset(size_t nblocks)
-{
-	return (sizeof(oroch_container_header) + (nblocks + 1) * sizeof(uint64_t) + 15) & ~size_t(15);
-}
-
-} // namespace
+using oroch_hip::CONTAINER_MAGIC;
+using oroch_hip::container_stream_offset;
 
 extern "C" size_t oroch_container_bound(int dtype, size_t n)
 {

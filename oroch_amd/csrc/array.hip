@@ -696,6 +696,119 @@ extern "C" int oroch_array_image(const oroch_array *a, uint64_t group, void *dst
 			     hipMemcpyDeviceToHost));
 }
 
+// ---- the array as a container -----------------------------------------------------------
+//
+// The full groups are the container's first blocks as they are; the tail, if
+// any, becomes its short last block.
+
+extern "C" size_t oroch_array_save_bound(const oroch_array *a)
+{
+	if (!a)
+		return 0;
+	const size_t ntail = a->in_tail();
+	return container_stream_offset(a->nblocks + (ntail ? 1 : 0)) + a->stream_bytes +
+	       (ntail ? oroch_group_bound(a->dtype, ntail) : 0);
+}
+
+static int save_array(const oroch_array *a, void *dst_host, size_t capacity, uint64_t *total_host)
+{
+	const size_t ntail = a->in_tail();
+	const size_t nb = a->nblocks + (ntail ? 1 : 0);
+	// the tail's image
+	std::vector<uint8_t> last(ntail ? oroch_group_bound(a->dtype, ntail) : 0);
+	uint64_t last_offs[2] = {0, 0}, last_len = 0;
+	int rc;
+	if (ntail && (rc = oroch_group_encode_host(a->dtype, a->tail.data(), ntail, last.data(), last.size(),
+						   last_offs, &last_len)))
+		return rc;
+	oroch_container_header h;
+	std::memset(&h, 0, sizeof h);
+	std::memcpy(h.magic, CONTAINER_MAGIC, sizeof h.magic);
+	h.dtype = uint32_t(a->dtype);
+	h.block_values = OROCH_BLOCK_VALUES;
+	h.nvalues = a->in_blocks() + ntail;
+	h.nblocks = nb;
+	h.table_offset = sizeof h;
+	h.stream_offset = container_stream_offset(nb);
+	h.stream_bytes = a->stream_bytes + last_len;
+	*total_host = h.stream_offset + h.stream_bytes;
+	if (*total_host > capacity)
+		return OROCH_E_CAPACITY;
+	uint8_t *out = static_cast<uint8_t *>(dst_host);
+	std::memcpy(out, &h, sizeof h);
+	uint64_t *table = reinterpret_cast<uint64_t *>(out + h.table_offset);
+	std::memset(table, 0, size_t(h.stream_offset - h.table_offset));
+	if (a->nblocks) {
+		if ((rc = int(hipMemcpy(table, a->offsets.p, (a->nblocks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost))) ||
+		    (rc = staged_copy(out + h.stream_offset, a->stream.p, a->stream_bytes, false, nullptr)))
+			return rc;
+	}
+	table[a->nblocks] = a->stream_bytes;
+	if (ntail) {
+		table[nb] = a->stream_bytes + last_len;
+		std::memcpy(out + h.stream_offset + a->stream_bytes, last.data(), size_t(last_len));
+	}
+	return 0;
+}
+
+extern "C" int oroch_array_save(const oroch_array *a, void *dst_host, size_t capacity, uint64_t *total_host)
+{
+	if (!a || !dst_host || !total_host)
+		return OROCH_E_ARGUMENT;
+	try {
+		return save_array(a, dst_host, capacity, total_host);
+	} catch (const std::bad_alloc &) {
+		return int(hipErrorOutOfMemory);
+	}
+}
+
+static int load_array(oroch_array *a, const void *src_host, size_t bytes)
+{
+	oroch_container_header h;
+	if (bytes < sizeof h)
+		return OROCH_E_ARGUMENT;
+	std::memcpy(&h, src_host, sizeof h);
+	int rc = oroch_container_check(&h, bytes);
+	if (rc)
+		return rc;
+	if (int(h.dtype) != a->dtype)
+		return OROCH_E_DTYPE;
+	const uint8_t *in = static_cast<const uint8_t *>(src_host);
+	const size_t nfull = size_t(h.nvalues / BLOCK), ntail = size_t(h.nvalues % BLOCK);
+	const size_t w = a->width();
+	// the table may be anything: the images of the full groups must end inside
+	// the stream at a multiple of 16 for appends to go on from there
+	uint64_t full_bytes = 0;
+	std::memcpy(&full_bytes, in + h.table_offset + nfull * sizeof(uint64_t), sizeof full_bytes);
+	if (full_bytes > h.stream_bytes || (full_bytes & 15u) || (nfull == 0 && full_bytes != 0))
+		return OROCH_E_ARGUMENT;
+	std::vector<uint8_t> tail(ntail * w);
+	if (ntail && (rc = oroch_container_decode_host(src_host, bytes, nfull, 1, tail.data())))
+		return rc;
+	if (nfull) {
+		if ((rc = grow(a->stream, a->stream_cap, size_t(full_bytes) + 16, 0)) ||
+		    (rc = grow(a->offsets, a->offsets_cap, (nfull + 1) * sizeof(uint64_t), 0)) ||
+		    (rc = staged_copy(a->stream.p, in + h.stream_offset, size_t(full_bytes), true, nullptr)) ||
+		    (rc = staged_copy(a->offsets.p, in + h.table_offset, (nfull + 1) * sizeof(uint64_t), true, nullptr)))
+			return rc;
+	}
+	a->nblocks = nfull;
+	a->stream_bytes = size_t(full_bytes);
+	a->tail.swap(tail);
+	return 0;
+}
+
+extern "C" int oroch_array_load(oroch_array *a, const void *src_host, size_t bytes)
+{
+	if (!a || !src_host)
+		return OROCH_E_ARGUMENT;
+	try {
+		return load_array(a, src_host, bytes);
+	} catch (const std::bad_alloc &) {
+		return int(hipErrorOutOfMemory);
+	}
+}
+
 extern "C" int oroch_array_find(oroch_array *a, const uint64_t *values, size_t m, uint64_t *index)
 {
 	if (!a || (m && (!values || !index)))

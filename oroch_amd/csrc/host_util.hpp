@@ -2,7 +2,10 @@
 #pragma once
 
 #include <cstddef>
+#include <cstdint>
 #include <hip/hip_runtime.h>
+
+#include "../../include/oroch_hip.h"
 
 namespace oroch_hip {
 
@@ -35,6 +38,14 @@ struct dev_buf
 		o.p = t;
 	}
 };
+
+// The serialised container: magic and where the block images start after the
+// header and the table of nblocks + 1 offsets.
+constexpr uint8_t CONTAINER_MAGIC[8] = {'O', 'R', 'O', 'C', 'H', 'B', 'K', '1'};
+inline size_t container_stream_offset(size_t nblocks)
+{
+	return (sizeof(oroch_container_header) + (nblocks + 1) * sizeof(uint64_t) + 15) & ~size_t(15);
+}
 
 // Copies between pageable host memory and the device, staged through pinned
 // buffers; returns after the data has arrived.  (api.hip)

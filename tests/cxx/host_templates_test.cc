@@ -536,6 +536,19 @@ static void test_array()
 		thrown = true;
 	}
 	REQUIRE(thrown);
+	// through a byte string and back; the bytes are the container of the same values
+	{
+		const std::vector<uint8_t> bytes = array.save();
+		oroch::integer_container<T> c;
+		c.encode(model.begin(), model.end());
+		REQUIRE(bytes == c.bytes());
+		oroch::integer_array<T> again;
+		again.load(bytes);
+		REQUIRE(again.size() == model.size());
+		REQUIRE(again.read(0, model.size()) == model);
+		again.insert(again.size(), T(5));
+		REQUIRE(again.at(model.size()) == T(5));
+	}
 	std::ostringstream os;
 	array.group_info(os);
 	const std::string text = os.str();

@@ -182,6 +182,38 @@ def test_growable_array(hip, oracle, dt):
     check_array(hip, oracle, arr, model[:600])
 
 
+@pytest.mark.parametrize("dt", [np.int8, np.uint16, np.int32, np.uint64])
+def test_array_as_container(hip, dt):
+    """save() gives the serialised container of the same values, byte for byte;
+    load() takes any such container and the array goes on from there."""
+    dt = np.dtype(dt)
+    rng = np.random.default_rng(404 + dt.itemsize)
+    for nblocks, last in ((7, 100), (3, 0), (0, 9), (0, 0)):
+        model = mixed_blocks(rng, dt, nblocks, last) if nblocks or last else np.empty(0, dt)
+        arr = hip.IntegerArray(dt)
+        arr.append(model[:model.size // 2])
+        arr.append(model[model.size // 2:])
+        blob = arr.save()
+        assert np.array_equal(blob, hip.container_encode_host(model)), (dt, nblocks, last)
+        other = hip.IntegerArray(dt)
+        other.append(mixed_blocks(rng, dt, 2, 5))      # replaced by load
+        other.load(blob)
+        assert len(other) == model.size and np.array_equal(other.read(), model)
+        more = mixed_blocks(rng, dt, 1, 30)
+        other.append(more)
+        grown = np.concatenate([model, more])
+        assert np.array_equal(other.read(), grown)
+        if grown.size:
+            v = grown[-1]
+            assert other.find(v) == int(np.flatnonzero(grown == v)[0])
+        assert np.array_equal(other.save(), hip.container_encode_host(grown))
+    wrong = hip.IntegerArray(np.int16 if dt != np.int16 else np.int32)
+    with pytest.raises(hip.OrochError):
+        wrong.load(blob)
+    with pytest.raises(hip.OrochError):
+        arr.load(blob[:40])
+
+
 def test_reference_array_scenarios(hip):
     """tests/unit/integer_array.cc: "small integer array" and "large integer array"."""
     arr = hip.IntegerArray(np.int32)
