@@ -204,6 +204,17 @@ int oroch_hip::staged_copy(void *dst, const void *src, size_t bytes, bool to_dev
 {
 	if (bytes == 0)
 		return 0;
+	// A caller's buffer that is pinned already (hipHostMalloc, hipHostRegister,
+	// torch's pin_memory) goes over the link as it is.
+	{
+		const void *host = to_device ? src : dst;
+		hipPointerAttribute_t attr;
+		if (hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost) {
+			int rc = int(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+			return rc ? rc : int(hipStreamSynchronize(st));
+		}
+		(void) hipGetLastError(); // an ordinary pointer is no error
+	}
 	std::lock_guard<std::mutex> guard(g_staging.lock);
 	const size_t CHUNK = staging::CHUNK;
 	int rc = g_staging.prepare();
