@@ -277,32 +277,32 @@ __global__ __launch_bounds__(PK_THREADS) void k_fetch(const uint64_t *src, size_
 
 // ---- bitpfr exception lists ---------------------------------------------------------
 //
-// A tile is 1024 consecutive values handled by one 256-thread workgroup, four
-// consecutive values per thread.
+// A tile is 16384 consecutive values handled by one 256-thread workgroup, one
+// 64-bit word of the exception map per thread.
 
 constexpr int XT_THREADS = 256;
-constexpr int XT_VPT = 16;
+constexpr int XT_VPT = 64;
 constexpr int XT_TILE = XT_THREADS * XT_VPT;
 constexpr uint64_t XT_NONE = ~uint64_t(0);
 
-// The 16 bits of the exception map for values base .. base + 15 (base a
-// multiple of 16).
-__device__ __forceinline__ uint32_t exc_flags(const uint64_t *map, size_t base)
+// The word of the exception map for values base .. base + 63 (base a multiple
+// of 64).
+__device__ __forceinline__ uint64_t exc_flags(const uint64_t *map, size_t base)
 {
-	return uint32_t(map[base / 64] >> (base % 64)) & 0xffffu;
+	return map[base / 64];
 }
 
-// Pass 1: per tile of 4096 values, the number of exceptions and the position
+// Pass 1: per tile of XT_TILE values, the number of exceptions and the position
 // of the last one.
 __global__ __launch_bounds__(XT_THREADS) void k_exc_count(const uint64_t *map, uint32_t *counts,
 							    uint64_t *last)
 {
 	__shared__ uint32_t wave_cnt[XT_THREADS / WAVE], wave_last[XT_THREADS / WAVE];
 	const size_t tile_base = size_t(blockIdx.x) * XT_TILE;
-	const uint32_t flags = exc_flags(map, tile_base + size_t(threadIdx.x) * XT_VPT);
-	const uint32_t cnt = wave_sum(uint32_t(__popc(flags)));
+	const uint64_t flags = exc_flags(map, tile_base + size_t(threadIdx.x) * XT_VPT);
+	const uint32_t cnt = wave_sum(uint32_t(__popcll(flags)));
 	// highest position in the tile with an exception, plus one; 0 = none
-	const uint32_t lp = wave_max(flags ? threadIdx.x * XT_VPT + (31u - uint32_t(__clz(flags))) + 1u : 0u);
+	const uint32_t lp = wave_max(flags ? threadIdx.x * XT_VPT + (63u - uint32_t(__clzll(flags))) + 1u : 0u);
 	if (lane_id() == 0) {
 		wave_cnt[threadIdx.x / WAVE] = cnt;
 		wave_last[threadIdx.x / WAVE] = lp;
@@ -353,11 +353,11 @@ __global__ __launch_bounds__(XT_THREADS) void k_exc_emit(const typename E::S *sr
 
 	const size_t tile_base = tile * XT_TILE;
 	const size_t base = tile_base + size_t(threadIdx.x) * XT_VPT;
-	uint32_t flags = exc_flags(map, base);
-	const uint32_t cnt = uint32_t(__popc(flags));
+	uint64_t flags = exc_flags(map, base);
+	const uint32_t cnt = uint32_t(__popcll(flags));
 	const uint32_t incl_cnt = wave_scan_sum(cnt, lane);
 	// last exception at or below this thread, as tile position + 1 (0 = none)
-	const int lp = flags ? int(threadIdx.x * XT_VPT + (31u - uint32_t(__clz(flags))) + 1u) : 0;
+	const int lp = flags ? int(threadIdx.x * XT_VPT + (63u - uint32_t(__clzll(flags))) + 1u) : 0;
 	const int incl_last = wave_scan_max(lp, lane);
 	if (lane == WAVE - 1) {
 		wave_cnt[wave] = incl_cnt;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(XT_THREADS) void k_exc_emit(const typename E::S *sr
 	// next expected position (offset.h:55-60): previous + 1, or 0 at the start
 	uint64_t next = prevp ? tile_base + uint64_t(prevp) : (before == XT_NONE ? 0 : before + 1);
 	while (flags) {
-		const uint64_t pos = base + uint64_t(__builtin_ctz(flags));
+		const uint64_t pos = base + uint64_t(__builtin_ctzll(flags));
 		flags &= flags - 1u;
 		if (rank < capacity) {
 			const C u = C((C(src[pos]) - origin) & E::MASK);
