@@ -122,6 +122,9 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_find(const uint8_t *__re
 {
 	using C = typename E::C;
 	const int lane = lane_id();
+	// a workgroup that starts after a lower block has reported has nothing to do
+	if (m == 1 && found_below(result, size_t(blockIdx.x) * WAVES_PER_WG))
+		return;
 	const C first = C(uniform(needles[0])) & E::MASK;
 	walk_blocks<E>(
 		src, offsets, n, nblocks,
@@ -144,6 +147,9 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 	const uint64_t *__restrict__ needles, size_t m, unsigned long long *result)
 {
 	using C = typename E::C;
+	// a workgroup that starts after a lower block has reported has nothing to do
+	if (m == 1 && found_below(result, size_t(blockIdx.x) * WAVES_PER_WG * QUAD))
+		return;
 	const C first = C(uniform(needles[0])) & E::MASK;
 	walk_quads<E>(
 		src, offsets, n, nblocks,
