@@ -16,6 +16,12 @@ class normal_codec
 public:
 	using original_t = T;
 
+	// normal.h:37-40
+	static constexpr size_t space(size_t nvalues)
+	{
+		return nvalues * sizeof(original_t);
+	}
+
 	template <typename Iter>
 	static void encode(dst_bytes_t &dst, Iter src, Iter const end)
 	{
