@@ -119,7 +119,7 @@ def test_bitpfr_exception_bookkeeping(oracle):
     assert np.array_equal(oracle.bitpfr_decode(out, c.size, 1000, 7, idx, val, np.uint32), c)
 
 
-def test_survey_known_answers(oracle):
+def test_worked_example_known_answers(oracle):
     # int32 ramp 3i-100 with one 2^30 spike: metadata bytes and data size
     a = (3 * np.arange(256) - 100).astype(np.int32)
     a[17] = 1 << 30
