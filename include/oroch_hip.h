@@ -435,6 +435,24 @@ enum {
 int oroch_hip_profile_start(int max_records);
 int oroch_hip_profile_stop(double *ms, unsigned *launches);
 
+/*
+ * Run-time switches between kernels that produce the same bytes, for tests and
+ * experiments (no counterpart in the reference).  Each starts from the
+ * environment variable OROCH_HIP_<NAME>, read once per process; set_option
+ * returns the previous value, or OROCH_E_ARGUMENT for an unknown switch.
+ */
+enum {
+	OROCH_OPT_ENCODE_PATH = 0,       /* 0 default; 1 select, scan, encode as separate launches;
+					    2 one block per wavefront in a single launch */
+	OROCH_OPT_SELECT_ONE_BLOCK = 1,  /* 1: one block per wavefront for every element type */
+	OROCH_OPT_ENCODE_ONE_BLOCK = 2,
+	OROCH_OPT_DECODE_ONE_BLOCK = 3,
+	OROCH_OPT_FIND_ONE_BLOCK = 4,
+	OROCH_OPT_COUNT = 5,
+};
+int oroch_hip_set_option(int option, int value);
+int oroch_hip_get_option(int option);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,8 @@ from .capi import (  # noqa: F401
     group_stats,
     group_workspace,
     lib,
+    option,
+    set_option,
     library_path,
     profile_start,
     profile_stop,

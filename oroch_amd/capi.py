@@ -109,6 +109,8 @@ def _load():
         "oroch_array_view": (i, [vp, vp, vp, vp, vp, vp, vp]),
         "oroch_hip_profile_start": (i, [i]),
         "oroch_hip_profile_stop": (i, [vp, vp]),
+        "oroch_hip_set_option": (i, [i, i]),
+        "oroch_hip_get_option": (i, [i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -280,6 +282,29 @@ def varint_decode(b, n, dtype):
 
 
 KERNEL_NAMES = ["select", "scan", "encode", "decode", "pack", "unpack", "except"]
+OPTIONS = {"encode_path": 0, "select_one_block": 1, "encode_one_block": 2, "decode_one_block": 3,
+           "find_one_block": 4}
+
+
+def set_option(name, value):
+    """Sets a run-time switch (OROCH_OPT_*) and returns its previous value."""
+    rc = lib.oroch_hip_set_option(OPTIONS[name], int(value))
+    if rc < 0:
+        _check(rc)
+    return rc
+
+
+class option:
+    """`with option("decode_one_block", 1): ...` restores the switch afterwards."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
 
 
 def profile_start(max_records=4096):

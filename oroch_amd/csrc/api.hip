@@ -1,6 +1,7 @@
 // api.hip -- library set-up, error text and the host-buffer entry points.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
@@ -100,6 +101,57 @@ extern "C" int oroch_hip_profile_stop(double *ms, unsigned *launches)
 	}
 	g_prof.clear();
 	return rc;
+}
+
+namespace oroch_hip {
+namespace {
+// The switches start from the environment, which is read once.
+struct option_table
+{
+	std::atomic<int> v[OROCH_OPT_COUNT];
+	option_table()
+	{
+		auto env = [](const char *name) {
+			const char *e = getenv(name);
+			return e && *e ? atoi(e) : 0;
+		};
+		int path = env("OROCH_HIP_ENCODE_PATH");
+		if (env("OROCH_HIP_TWO_PASS"))
+			path = 1;
+		else if (env("OROCH_HIP_SINGLE_PASS"))
+			path = 2;
+		v[OROCH_OPT_ENCODE_PATH] = path;
+		v[OROCH_OPT_SELECT_ONE_BLOCK] = env("OROCH_HIP_SELECT_ONE_BLOCK");
+		v[OROCH_OPT_ENCODE_ONE_BLOCK] = env("OROCH_HIP_ENCODE_ONE_BLOCK");
+		v[OROCH_OPT_DECODE_ONE_BLOCK] = env("OROCH_HIP_DECODE_ONE_BLOCK");
+		v[OROCH_OPT_FIND_ONE_BLOCK] = env("OROCH_HIP_FIND_ONE_BLOCK");
+	}
+};
+option_table &options()
+{
+	static option_table t;
+	return t;
+}
+} // namespace
+
+int option(int id)
+{
+	return options().v[id].load(std::memory_order_relaxed);
+}
+} // namespace oroch_hip
+
+extern "C" int oroch_hip_set_option(int option, int value)
+{
+	if (option < 0 || option >= OROCH_OPT_COUNT)
+		return OROCH_E_ARGUMENT;
+	return oroch_hip::options().v[option].exchange(value);
+}
+
+extern "C" int oroch_hip_get_option(int option)
+{
+	if (option < 0 || option >= OROCH_OPT_COUNT)
+		return OROCH_E_ARGUMENT;
+	return oroch_hip::option(option);
 }
 
 extern "C" int oroch_hip_init(int device)

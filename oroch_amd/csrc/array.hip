@@ -410,9 +410,8 @@ extern "C" int oroch_group_find(int dtype, const void *src, const uint64_t *offs
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		if constexpr (sizeof(typename E::C) == 4) {
-			// OROCH_HIP_FIND_ONE_BLOCK=1 keeps to the one-block walker (tests)
-			const char *v = getenv("OROCH_HIP_FIND_ONE_BLOCK");
-			if (!(v && *v && *v != '0')) {
+			// OROCH_OPT_FIND_ONE_BLOCK keeps to the one-block walker (tests)
+			if (!option(OROCH_OPT_FIND_ONE_BLOCK)) {
 				hipLaunchKernelGGL(k_find_quad<E>, dim3(walk_grid((nb + QUAD - 1) / QUAD)),
 						   dim3(WAVE * WAVES_PER_WG), 0, st, static_cast<const uint8_t *>(src),
 						   offsets, n, nb, values, m, reinterpret_cast<unsigned long long *>(index));

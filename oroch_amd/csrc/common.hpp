@@ -98,6 +98,9 @@ struct profile_scope
 	}
 };
 
+// Value of a run-time switch (OROCH_OPT_*); api.hip.
+int option(int id);
+
 #ifdef __HIPCC__
 
 __constant__ const width_table g_width = make_width_table();

@@ -1107,33 +1107,25 @@ static int fused_resident_workgroups()
 	return cached;
 }
 
-// Which encode path runs: the single-pass kernel reads the values once but
-// currently loses more to its lower occupancy and the look-back waits than it
-// saves, so the two-pass path (select, scan, encode) is the default.
-// OROCH_HIP_SINGLE_PASS=1 selects the single-pass kernel, OROCH_HIP_TWO_PASS=1
-// forces the default explicitly.
-// OROCH_HIP_DECODE_ONE_BLOCK=1 keeps the one-block-per-wavefront decoder for
-// every element type (the 64-bit types always use it); read per call so that
+// Which encode path runs (OROCH_OPT_ENCODE_PATH): the single-pass kernel reads
+// the values once but currently loses more to its lower occupancy and the
+// look-back waits than it saves, so the two-pass path (select, scan, encode) is
+// the default.  The *_ONE_BLOCK switches keep the one-block-per-wavefront
+// kernels for every element type (the 64-bit types always use them), so that
 // tests can compare the two.
 static bool one_block_decode_forced()
 {
-	const char *v = getenv("OROCH_HIP_DECODE_ONE_BLOCK");
-	return v && v[0] == '1';
+	return option(OROCH_OPT_DECODE_ONE_BLOCK) != 0;
 }
 
 static bool one_block_encode_forced()
 {
-	const char *v = getenv("OROCH_HIP_ENCODE_ONE_BLOCK");
-	return v && v[0] == '1';
+	return option(OROCH_OPT_ENCODE_ONE_BLOCK) != 0;
 }
 
 static bool two_pass_forced()
 {
-	const char *e = getenv("OROCH_HIP_TWO_PASS");
-	if (e && e[0] == '1')
-		return true;
-	const char *s = getenv("OROCH_HIP_SINGLE_PASS");
-	return !(s && s[0] == '1');
+	return option(OROCH_OPT_ENCODE_PATH) != 2;
 }
 
 } // namespace oroch_hip
@@ -1141,15 +1133,14 @@ static bool two_pass_forced()
 using namespace oroch_hip;
 
 // Launches the selection pass: four blocks per wavefront for element types up
-// to 32 bits (unless OROCH_HIP_SELECT_ONE_BLOCK=1), one block per wavefront
+// to 32 bits (unless OROCH_OPT_SELECT_ONE_BLOCK is set), one block per wavefront
 // otherwise.
 template <typename E>
 static int launch_select(const void *src, size_t n, size_t nb, oroch_block_desc *desc, uint32_t *sizes,
 			 hipStream_t st)
 {
 	if constexpr (sizeof(typename E::C) == 4) {
-		const char *v = getenv("OROCH_HIP_SELECT_ONE_BLOCK");
-		if (!(v && v[0] == '1')) {
+		if (!option(OROCH_OPT_SELECT_ONE_BLOCK)) {
 			const size_t nq = (nb + QUAD - 1) / QUAD;
 			unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
 			qgrid = qgrid < 16384u ? qgrid : 16384u;
@@ -1229,9 +1220,9 @@ extern "C" int oroch_group_stats(int dtype, const void *src, size_t n, oroch_blo
 	});
 }
 
-extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *dst,
-				  size_t dst_capacity, uint64_t *offsets, void *workspace,
-				  size_t workspace_bytes, uint64_t *total_host, void *stream)
+static int group_encode_impl(int dtype, const void *src, size_t n, void *dst, size_t dst_capacity,
+			     uint64_t *offsets, void *workspace, size_t workspace_bytes,
+			     uint64_t *total_host, void *stream)
 {
 	if (dtype < 0 || dtype > 7)
 		return OROCH_E_DTYPE;
@@ -1341,6 +1332,14 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 	return rc;
 }
 
+
+extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *dst,
+				  size_t dst_capacity, uint64_t *offsets, void *workspace,
+				  size_t workspace_bytes, uint64_t *total_host, void *stream)
+{
+	return group_encode_impl(dtype, src, n, dst, dst_capacity, offsets, workspace, workspace_bytes,
+				 total_host, stream);
+}
 
 extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n,
 				  void *dst, void *stream)

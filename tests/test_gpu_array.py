@@ -61,7 +61,7 @@ def some_needles(rng, a, dt, count):
 
 
 @pytest.mark.parametrize("dt", ALL)
-def test_find_and_at_over_block_images(hip, dt, monkeypatch):
+def test_find_and_at_over_block_images(hip, dt):
     dt = np.dtype(dt)
     rng = np.random.default_rng(9100 + dt.itemsize * 2 + (dt.kind == "u"))
     for nblocks, last in ((37, 0), (12, 77), (0, 5), (1, 0)):
@@ -76,11 +76,10 @@ def test_find_and_at_over_block_images(hip, dt, monkeypatch):
         for v, w in zip(needles[::3], want[::3]):
             assert int(hip.group_find(stream, offs, a.size, dt, [v])[0]) == int(w), (dt, v)
         # the one-block-per-wavefront walker (the only one for 64-bit types) agrees
-        monkeypatch.setenv("OROCH_HIP_FIND_ONE_BLOCK", "1")
-        assert np.array_equal(hip.group_find(stream, offs, a.size, dt, needles), want)
-        for v, w in zip(needles[1::3], want[1::3]):
-            assert int(hip.group_find(stream, offs, a.size, dt, [v])[0]) == int(w), (dt, v)
-        monkeypatch.delenv("OROCH_HIP_FIND_ONE_BLOCK")
+        with hip.option("find_one_block", 1):
+            assert np.array_equal(hip.group_find(stream, offs, a.size, dt, needles), want)
+            for v, w in zip(needles[1::3], want[1::3]):
+                assert int(hip.group_find(stream, offs, a.size, dt, [v])[0]) == int(w), (dt, v)
         # random access, positions beyond the end included
         pos = np.concatenate([rng.integers(0, a.size, size=200), [0, a.size - 1, a.size, a.size + 999]])
         got = host(hip.group_at(stream, offs, a.size, dt, pos)).view(dt)
@@ -92,12 +91,17 @@ def test_find_and_at_over_block_images(hip, dt, monkeypatch):
         assert np.array_equal(every, a), (dt, nblocks, last, np.flatnonzero(every != a)[:8])
 
 
-@pytest.mark.parametrize("one_block", ["0", "1"])
-def test_find_shortcut_cases(hip, monkeypatch, one_block):
+@pytest.fixture
+def find_one_block(hip, request):
+    with hip.option("find_one_block", request.param):
+        yield request.param
+
+
+@pytest.mark.parametrize("find_one_block", [0, 1], indirect=True)
+def test_find_shortcut_cases(hip, find_one_block):
     """Blocks built so that the metadata alone rules the value in or out
     (integer_array.h:85-126): a constant block, narrow zigzag blocks, narrow
     blocks above an origin, and the value just outside each of them."""
-    monkeypatch.setenv("OROCH_HIP_FIND_ONE_BLOCK", one_block)
     dt = np.dtype(np.int32)
     rng = np.random.default_rng(77)
     const = np.full(256, -123456, dt)

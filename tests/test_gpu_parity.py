@@ -257,19 +257,14 @@ def test_argument_errors(hip):
 def test_two_pass_path_matches_single_pass(hip, oracle):
     # the single-pass kernel (chained scan inside one launch) and the two-pass
     # path (select, scan, encode as separate launches) give the same stream
-    import os
-
     a = np.concatenate([dg.outlier_mix(256 * 999 + 17, np.int32, seed=11, shift=-200),
                         dg.fuzz_block(np.random.default_rng(5), np.int32, 256)])
     x = dev(a)
     s1, o1 = hip.group_encode(x)
-    os.environ["OROCH_HIP_SINGLE_PASS"] = "1"
-    try:
+    with hip.option("encode_path", 2):
         s2, o2 = hip.group_encode(x)
         big = dev(dg.outlier_mix(1 << 24, np.int32, seed=12, shift=-200))
         b2, bo2 = hip.group_encode(big)
-    finally:
-        del os.environ["OROCH_HIP_SINGLE_PASS"]
     b1, bo1 = hip.group_encode(big)
     assert np.array_equal(host(bo1), host(bo2)) and np.array_equal(host(b1), host(b2))
     assert np.array_equal(host(o1), host(o2)) and np.array_equal(host(s1), host(s2))
@@ -295,7 +290,7 @@ def test_block_statistics_against_oracle(hip, oracle, dt):
 
 
 @pytest.mark.parametrize("dt", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32])
-def test_four_block_decoder_paths(hip, oracle, dt, monkeypatch):
+def test_four_block_decoder_paths(hip, oracle, dt):
     """Streams whose blocks share a width, so that the four-blocks-per-wavefront
     decoder takes its fast path: every width, frame of reference or zigzag,
     no exceptions / a few (varint lists) / many (bit-packed lists)."""
@@ -335,9 +330,8 @@ def test_four_block_decoder_paths(hip, oracle, dt, monkeypatch):
     back = hip.group_decode(stream, offs, a.size, dt)
     assert np.array_equal(host(back).view(dt), a)
     # the one-block-per-wavefront decoder agrees
-    monkeypatch.setenv("OROCH_HIP_DECODE_ONE_BLOCK", "1")
-    back1 = hip.group_decode(stream, offs, a.size, dt)
-    monkeypatch.delenv("OROCH_HIP_DECODE_ONE_BLOCK")
+    with hip.option("decode_one_block", 1):
+        back1 = hip.group_decode(stream, offs, a.size, dt)
     assert torch.equal(back1, back)
     # a stream that does not end on a four-block boundary, with a short last block
     for cut in (256 * 5 + 17, 256 * 2, 255, 1):

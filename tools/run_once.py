@@ -9,8 +9,7 @@ x = gen_outlier_mix_torch(n, 3, "cuda")
 enc = oroch_amd.GroupEncoder(np.int32, n, x.device)
 back = torch.empty_like(x)
 for mode in ("two", "one"):
-    if mode == "two": os.environ.pop("OROCH_HIP_SINGLE_PASS", None)
-    else: os.environ["OROCH_HIP_SINGLE_PASS"] = "1"
+    oroch_amd.set_option("encode_path", 1 if mode == "two" else 2)
     for it in range(2):
         enc.encode(x)
         oroch_amd.lib.oroch_group_decode(4, enc.out.data_ptr(), enc.offsets.data_ptr(), n, back.data_ptr(), oroch_amd.capi._stream())

@@ -11,8 +11,7 @@ enc = oroch_amd.GroupEncoder(np.int32, n, x.device)
 back = torch.empty_like(x)
 res = {}
 for mode in ("two", "one"):
-    if mode == "two": os.environ.pop("OROCH_HIP_SINGLE_PASS", None)
-    else: os.environ["OROCH_HIP_SINGLE_PASS"] = "1"
+    oroch_amd.set_option("encode_path", 1 if mode == "two" else 2)
     for it in range(2): enc.encode(x)
     torch.cuda.synchronize()
     oroch_amd.profile_start(256)
