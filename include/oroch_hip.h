@@ -47,6 +47,7 @@ enum {
 	OROCH_E_ARGUMENT = -5,  /* null pointer or inconsistent sizes */
 	OROCH_E_NOGPU = -6,     /* no usable HIP device */
 	OROCH_E_RANGE = -7,     /* position outside the array */
+	OROCH_E_TOO_LARGE = -8, /* beyond the fixed maximum of a non-allocating entry point */
 };
 
 /* Values per block of the batch (group) entry points; integer_array.h:44. */
@@ -216,6 +217,23 @@ size_t oroch_group_workspace(int dtype, size_t n);
 int oroch_group_encode(int dtype, const void *src, size_t n, void *dst, size_t dst_capacity,
 		       uint64_t *offsets, void *workspace, size_t workspace_bytes,
 		       uint64_t *total_host, void *stream);
+
+/*
+ * oroch_group_encode without a workspace argument and without any allocation,
+ * for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * The workspace is a fixed 4 MiB device array inside the library (one copy per
+ * GPU, held until the process ends), which limits a call to
+ * oroch_group_encode_static_max(dtype) = 2^24 values; more gives
+ * OROCH_E_TOO_LARGE.  Same stream bytes and offsets as oroch_group_encode; the
+ * stream length is offsets[ceil(n / block)] on the device.  All calls on one GPU
+ * share that GPU's array: calls that overlap in time on one GPU (different
+ * streams or threads) race and must be serialised by the caller.  Kernel-time
+ * recording (oroch_hip_profile_start) skips this entry point.
+ */
+size_t oroch_group_encode_static_max(int dtype);
+int oroch_group_encode_static(int dtype, const void *src, size_t n, void *dst, size_t dst_capacity,
+			      uint64_t *offsets, void *stream);
 
 /*
  * integer_group<T>::decode, integer_group.h:62-76, for every block of a

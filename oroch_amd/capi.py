@@ -74,6 +74,8 @@ def _load():
         "oroch_group_workspace": (sz, [i, sz]),
         "oroch_group_encode": (i, [i, vp, sz, vp, sz, vp, vp, sz, vp, vp]),
         "oroch_group_decode": (i, [i, vp, vp, sz, vp, vp]),
+        "oroch_group_encode_static": (i, [i, vp, sz, vp, sz, vp, vp]),
+        "oroch_group_encode_static_max": (sz, [i]),
         "oroch_group_encode_host": (i, [i, vp, sz, vp, sz, vp, vp]),
         "oroch_group_decode_host": (i, [i, vp, vp, sz, vp]),
         "oroch_group_stats": (i, [i, vp, sz, vp, vp]),

@@ -20,14 +20,24 @@ struct record
 	hipEvent_t begin, end;
 };
 std::mutex g_prof_lock;
+thread_local int g_prof_quiet = 0;
 bool g_prof_on = false;
 size_t g_prof_max = 0;
 std::vector<record> g_prof;
 } // namespace
 
+no_profile_scope::no_profile_scope()
+{
+	g_prof_quiet++;
+}
+no_profile_scope::~no_profile_scope()
+{
+	g_prof_quiet--;
+}
+
 void profile_mark(int kernel_id, hipStream_t st, bool begin)
 {
-	if (!g_prof_on)
+	if (!g_prof_on || g_prof_quiet)
 		return;
 	std::lock_guard<std::mutex> lock(g_prof_lock);
 	if (!g_prof_on)
@@ -172,7 +182,8 @@ extern "C" int oroch_hip_init(int device)
 	// the kernels are compiled for gfx950 (64-lane wavefronts) only
 	if (prop.warpSize != 64 || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
 		return OROCH_E_NOGPU;
-	return 0;
+	// this device's copy of the scratch array of the non-allocating entry point
+	return oroch_hip::static_scratch_setup(nullptr);
 }
 
 extern "C" const char *oroch_hip_strerror(int code)
@@ -186,6 +197,7 @@ extern "C" const char *oroch_hip_strerror(int code)
 	case OROCH_E_ARGUMENT: return "null / misaligned pointer or inconsistent sizes";
 	case OROCH_E_NOGPU: return "no usable gfx950 HIP device";
 	case OROCH_E_RANGE: return "position outside the array";
+	case OROCH_E_TOO_LARGE: return "more values than the fixed scratch buffer of the non-allocating entry point holds";
 	}
 	if (code > 0)
 		return hipGetErrorString(hipError_t(code));

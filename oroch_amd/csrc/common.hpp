@@ -101,6 +101,18 @@ struct profile_scope
 // Value of a run-time switch (OROCH_OPT_*); api.hip.
 int option(int id);
 
+// While one of these is alive on a thread, profile_scope records nothing there
+// (recording creates events, which allocates).
+struct no_profile_scope
+{
+	no_profile_scope();
+	~no_profile_scope();
+};
+
+// Device address of the scratch array behind oroch_group_encode_static on the
+// current device, looked up on the first call per device; group.hip.
+int static_scratch_setup(void **ptr);
+
 #ifdef __HIPCC__
 
 __constant__ const width_table g_width = make_width_table();

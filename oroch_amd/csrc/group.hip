@@ -12,6 +12,7 @@
 //   integer_group.h:44-76                  [meta][pad to 8][data] framing
 //   bitpck.h:73-201, varint.h:74-115       16-byte block packing, varints
 #include <cstdlib>
+#include <mutex>
 
 #include "common.hpp"
 #include "bitfield.hpp"
@@ -1339,6 +1340,78 @@ extern "C" int oroch_group_encode(int dtype, const void *src, size_t n, void *ds
 {
 	return group_encode_impl(dtype, src, n, dst, dst_capacity, offsets, workspace, workspace_bytes,
 				 total_host, stream);
+}
+
+// ---- batch encode without allocation -----------------------------------------------
+//
+// The workspace of the encoder (descriptors, sizes, scan and look-back state) in
+// a device array of this code object instead of caller memory, for callers that
+// cannot allocate.  Every GPU holds its own copy of the array at its own
+// address: that address is looked up once per device and kept.
+
+namespace oroch_hip {
+
+constexpr size_t STATIC_SCRATCH_BYTES = size_t(4) << 20;
+constexpr size_t STATIC_MAX_VALUES = size_t(1) << 24;
+constexpr int STATIC_MAX_DEVICES = 64;
+
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+static std::mutex g_scratch_lock;
+static void *g_scratch_ptr[STATIC_MAX_DEVICES]; // device address of `scratch`, per device
+
+// Looks up the current device's copy of the scratch array (first call per
+// device) and returns its device address through *ptr.
+int static_scratch_setup(void **ptr)
+{
+	int dev = -1;
+	int rc = int(hipGetDevice(&dev));
+	if (rc)
+		return rc;
+	if (dev < 0 || dev >= STATIC_MAX_DEVICES)
+		return OROCH_E_ARGUMENT;
+	std::lock_guard<std::mutex> guard(g_scratch_lock);
+	if (!g_scratch_ptr[dev]) {
+		void *p = nullptr;
+		rc = int(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+		if (rc)
+			return rc;
+		if (!p || (reinterpret_cast<uintptr_t>(p) & 255u))
+			return int(hipErrorInvalidSymbol);
+		g_scratch_ptr[dev] = p;
+	}
+	if (ptr)
+		*ptr = g_scratch_ptr[dev];
+	return 0;
+}
+
+} // namespace oroch_hip
+
+extern "C" size_t oroch_group_encode_static_max(int dtype)
+{
+	if (dtype < 0 || dtype > 7)
+		return 0;
+	static_assert(STATIC_MAX_VALUES % BLOCK == 0, "whole blocks");
+	return carve_ws(nullptr, STATIC_MAX_VALUES).bytes <= STATIC_SCRATCH_BYTES ? STATIC_MAX_VALUES : 0;
+}
+
+extern "C" int oroch_group_encode_static(int dtype, const void *src, size_t n, void *dst,
+					 size_t dst_capacity, uint64_t *offsets, void *stream)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n > oroch_group_encode_static_max(dtype))
+		return OROCH_E_TOO_LARGE;
+	void *ws = nullptr;
+	const int rc = static_scratch_setup(&ws);
+	if (rc)
+		return rc;
+	// Nothing of an earlier call is carried over: descriptors and sizes are
+	// written for every block before they are read, the look-back state is
+	// cleared by the encoder itself.
+	no_profile_scope quiet; // recording creates events
+	return group_encode_impl(dtype, src, n, dst, dst_capacity, offsets, ws, STATIC_SCRATCH_BYTES, nullptr,
+				 stream);
 }
 
 extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n,
