@@ -461,7 +461,8 @@ int oroch_hip_profile_stop(double *ms, unsigned *launches);
  */
 enum {
 	OROCH_OPT_ENCODE_PATH = 0,       /* 0 default; 1 select, scan, encode as separate launches;
-					    2 one block per wavefront in a single launch */
+					    2 one block per wavefront in a single launch;
+					    3 four blocks per wavefront in a single launch */
 	OROCH_OPT_SELECT_ONE_BLOCK = 1,  /* 1: one block per wavefront for every element type */
 	OROCH_OPT_ENCODE_ONE_BLOCK = 2,
 	OROCH_OPT_DECODE_ONE_BLOCK = 3,

@@ -39,6 +39,9 @@ template <typename F>
 inline int dispatch_dtype(int dtype, F &&f)
 {
 	switch (dtype) {
+#ifdef OROCH_ONLY_I32 // experiment builds: int32 alone compiles in a sixth of the time
+	case OROCH_I32: return f(elem<32, true>{});
+#else
 	case OROCH_I8: return f(elem<8, true>{});
 	case OROCH_U8: return f(elem<8, false>{});
 	case OROCH_I16: return f(elem<16, true>{});
@@ -47,6 +50,7 @@ inline int dispatch_dtype(int dtype, F &&f)
 	case OROCH_U32: return f(elem<32, false>{});
 	case OROCH_I64: return f(elem<64, true>{});
 	case OROCH_U64: return f(elem<64, false>{});
+#endif
 	}
 	return OROCH_E_DTYPE;
 }

@@ -11,8 +11,10 @@
 //   integer_codec.h:386-402, 498-609       encode / decode dispatch, bitpfr lists
 //   integer_group.h:44-76                  [meta][pad to 8][data] framing
 //   bitpck.h:73-201, varint.h:74-115       16-byte block packing, varints
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 #include "common.hpp"
 #include "bitfield.hpp"
@@ -1029,6 +1031,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__
 #include "decode_quad.hpp"
 #include "encode_quad.hpp"
 #include "select_quad.hpp"
+#include "fused_quad.hpp"
 
 namespace oroch_hip {
 
@@ -1053,6 +1056,10 @@ struct group_ws
 	uint32_t *abort_flag;  // 16 bytes, directly in front of state (one memset)
 	uint64_t *state;       // one word per tile of the single-pass kernel
 	size_t state_bytes;    // abort word + state, a multiple of 16
+	// the four-blocks-per-wavefront single launch: abort word, A, S, P (one memset)
+	uint32_t *fq_abort;
+	fq_state fq;
+	size_t fq_bytes, fq_rows;
 	size_t bytes;
 };
 
@@ -1077,6 +1084,21 @@ static group_ws carve_ws(void *ws, size_t n)
 	w.state = reinterpret_cast<uint64_t *>(p + off + 16);
 	w.state_bytes = align_up(16 + max_tiles * sizeof(uint64_t), 16);
 	off = align_up(off + w.state_bytes, 256);
+	{
+		// a row per round of the single launch's table, for the fewest workgroups
+		// it may run with (one)
+		const size_t ntiles = (nb + QUAD - 1) / QUAD;
+		// (the launch takes one workgroup per CU; a device with fewer than 64 CUs
+		// falls back to the separate launches for arrays this does not cover)
+		const size_t max_rounds = ntiles / (size_t(FQ_WORKERS) * 64) + 2;
+		w.fq_abort = reinterpret_cast<uint32_t *>(p + off);
+		w.fq.abort_flag = w.fq_abort;
+		w.fq.rows = reinterpret_cast<uint16_t *>(p + off + 128);
+		w.fq.dbg = nullptr;
+		w.fq_rows = max_rounds;
+		w.fq_bytes = 128 + max_rounds * FQ_MAX_GROUPS * sizeof(uint16_t);
+		off = align_up(off + w.fq_bytes, 256);
+	}
 	w.bytes = off;
 	return w;
 }
@@ -1122,11 +1144,6 @@ static bool one_block_decode_forced()
 static bool one_block_encode_forced()
 {
 	return option(OROCH_OPT_ENCODE_ONE_BLOCK) != 0;
-}
-
-static bool two_pass_forced()
-{
-	return option(OROCH_OPT_ENCODE_PATH) != 2;
 }
 
 } // namespace oroch_hip
@@ -1309,8 +1326,53 @@ static int group_encode_impl(int dtype, const void *src, size_t n, void *dst, si
 			return int(hipGetLastError());
 		});
 	};
-	const bool force_two_pass = two_pass_forced();
-	rc = force_two_pass ? two_pass() : single_pass();
+	auto fused_quad = [&]() {
+		return dispatch_dtype(dtype, [&](auto e) {
+			using E = decltype(e);
+			if constexpr (sizeof(typename E::C) == 4) {
+				const size_t ntiles = (nb + QUAD - 1) / QUAD;
+				const int resident = fq_resident_workgroups<E>();
+				if (resident <= 0)
+					return int(hipErrorInvalidValue);
+				const size_t want = (ntiles + FQ_WORKERS - 1) / FQ_WORKERS;
+				const unsigned grid = unsigned(want < size_t(resident) ? want : size_t(resident));
+				const size_t per_round = size_t(grid) * FQ_WORKERS;
+				if ((ntiles + per_round - 1) / per_round > w.fq_rows)
+					return two_pass();
+				int r = int(hipMemsetAsync(w.fq_abort, 0, w.fq_bytes, st));
+				if (r)
+					return r;
+				{
+					profile_scope ps(OROCH_K_ENCODE, st);
+					hipLaunchKernelGGL(k_fused_quad<E>, dim3(grid), dim3(FQ_THREADS), 0, st,
+							   static_cast<const typename E::S *>(src), n, nb, ntiles,
+							   static_cast<uint8_t *>(dst), offsets, w.fq);
+					r = int(hipGetLastError());
+				}
+				if (r)
+					return r;
+#ifdef FQ_STATS
+				{
+					unsigned long long h[32];
+					(void) hipDeviceSynchronize();
+					(void) hipMemcpyFromSymbol(h, HIP_SYMBOL(fq_stats), sizeof h);
+					fprintf(stderr, "fq tiles %zu, grid %u: exchanger polls %llu (ok %llu, not yet %llu; %llu cycles for the loads); workers per tile in cycles: waited %llu (%llu waits), values %llu, select %llu, to publish %llu, to encode %llu, encode %llu, all %llu\n",
+						ntiles, grid, h[0], h[1], h[5], h[0] ? h[18] * 16 / h[0] : 0, h[10] * 16 / ntiles, h[4],
+						h[12] * 16 / ntiles, h[13] * 16 / ntiles, h[2] * 16 / ntiles, h[3] * 16 / ntiles, h[14] * 16 / ntiles, h[11] * 16 / ntiles);
+					unsigned long long z[32] = {0};
+					(void) hipMemcpyToSymbol(HIP_SYMBOL(fq_stats), z, sizeof z);
+				}
+#endif
+				hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, st, w.fq_abort, offsets, nb);
+				return int(hipGetLastError());
+			} else {
+				return single_pass();
+			}
+		});
+	};
+	const int path = option(OROCH_OPT_ENCODE_PATH);
+	const bool force_two_pass = path != 2 && path != 3;
+	rc = force_two_pass ? two_pass() : path == 3 ? fused_quad() : single_pass();
 	if (rc == 0 && total_host && !force_two_pass) {
 		// the only place the host can see that the single-pass kernel gave up
 		uint64_t total = 0;
