@@ -656,13 +656,28 @@ extern "C" int oroch_container_check(const oroch_container_header *h, size_t con
 		return OROCH_E_ARGUMENT;
 	if (h->dtype > 7u || h->block_values != OROCH_BLOCK_VALUES || h->reserved != 0)
 		return OROCH_E_ARGUMENT;
-	const uint64_t nblocks = (h->nvalues + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
-	if (h->nblocks != nblocks || h->table_offset != sizeof *h ||
+	// no sum that could wrap: a count near 2^64 must not come out as few blocks
+	const uint64_t nblocks = h->nvalues / OROCH_BLOCK_VALUES + (h->nvalues % OROCH_BLOCK_VALUES != 0);
+	// the table alone needs 8 bytes per block inside the container
+	if (h->nblocks != nblocks || nblocks > container_bytes / sizeof(uint64_t) || h->table_offset != sizeof *h ||
 	    h->stream_offset != container_stream_offset(size_t(nblocks)) || (h->stream_bytes & 15u))
 		return OROCH_E_ARGUMENT;
 	if (h->stream_bytes > container_bytes || h->stream_offset > container_bytes - h->stream_bytes)
 		return OROCH_E_ARGUMENT;
 	return 0;
+}
+
+bool oroch_hip::offsets_table_sound(const uint64_t *table, size_t entries, uint64_t stream_bytes)
+{
+	uint64_t before = 0;
+	for (size_t i = 0; i < entries; i++) {
+		uint64_t x;
+		memcpy(&x, reinterpret_cast<const uint8_t *>(table) + i * sizeof x, sizeof x); // any alignment
+		if (x < before || x > stream_bytes || (x & 15u))
+			return false;
+		before = x;
+	}
+	return true;
 }
 
 extern "C" int oroch_container_decode(const void *src, const oroch_container_header *h,
@@ -684,10 +699,11 @@ extern "C" int oroch_container_decode(const void *src, const oroch_container_hea
 	uint64_t hi = uint64_t(first_block + nblocks) * OROCH_BLOCK_VALUES;
 	hi = hi < h->nvalues ? hi : h->nvalues;
 	// the table's offsets are relative to the first image, which is what the
-	// decoder adds them to
-	return oroch_group_decode(int(h->dtype), base + h->stream_offset,
-				  reinterpret_cast<const uint64_t *>(base + h->table_offset) + first_block,
-				  size_t(hi - lo), dst, stream);
+	// decoder adds them to; the table is device memory nobody has looked at,
+	// so the decoder keeps every block inside the stream's length
+	return oroch_hip::group_decode_within(int(h->dtype), base + h->stream_offset,
+					      reinterpret_cast<const uint64_t *>(base + h->table_offset) + first_block,
+					      size_t(hi - lo), dst, h->stream_bytes, stream);
 }
 
 extern "C" int oroch_container_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
@@ -731,6 +747,13 @@ extern "C" int oroch_container_decode_host(const void *src_host, size_t containe
 	if (nblocks == 0)
 		return 0;
 	if (!dst_host)
+		return OROCH_E_ARGUMENT;
+	// the table is at hand here: a damaged one is an error, not wrong values
+	const uint8_t *table = static_cast<const uint8_t *>(src_host) + h.table_offset;
+	uint64_t table0;
+	memcpy(&table0, table, sizeof table0);
+	if (table0 != 0 || !oroch_hip::offsets_table_sound(reinterpret_cast<const uint64_t *>(table) + first_block,
+							   nblocks + 1, h.stream_bytes))
 		return OROCH_E_ARGUMENT;
 	const uint64_t lo = uint64_t(first_block) * OROCH_BLOCK_VALUES;
 	uint64_t hi = uint64_t(first_block + nblocks) * OROCH_BLOCK_VALUES;

@@ -116,7 +116,7 @@ __device__ __forceinline__ void report_hits(size_t blk, int nv, int lane, const 
 template <typename E>
 __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_find(const uint8_t *__restrict__ src,
 							       const uint64_t *__restrict__ offsets,
-							       size_t n, size_t nblocks,
+							       size_t n, size_t nblocks, uint64_t stream_limit,
 							       const uint64_t *__restrict__ needles, size_t m,
 							       unsigned long long *result)
 {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_find(const uint8_t *__re
 		return;
 	const C first = C(uniform(needles[0])) & E::MASK;
 	walk_blocks<E>(
-		src, offsets, n, nblocks,
+		src, offsets, n, nblocks, stream_limit,
 		[&](size_t blk, const uint32_t *img, uint32_t) {
 			if (m != 1)
 				return WALK_DECODE;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_find(const uint8_t *__re
 template <typename E>
 __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_find_quad(
 	const uint8_t *__restrict__ src, const uint64_t *__restrict__ offsets, size_t n, size_t nblocks,
-	const uint64_t *__restrict__ needles, size_t m, unsigned long long *result)
+	uint64_t stream_limit, const uint64_t *__restrict__ needles, size_t m, unsigned long long *result)
 {
 	using C = typename E::C;
 	// a workgroup that starts after a lower block has reported has nothing to do
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 		return;
 	const C first = C(uniform(needles[0])) & E::MASK;
 	walk_quads<E>(
-		src, offsets, n, nblocks,
+		src, offsets, n, nblocks, stream_limit,
 		[&](size_t blk) { return m == 1 && found_below(result, blk) ? WALK_STOP : WALK_DECODE; },
 		[&](size_t blk, int nv, int lane, const C(&v)[VPL]) {
 			report_hits<E>(blk, nv, lane, v, needles, m, first, result);
@@ -302,8 +302,9 @@ __device__ __forceinline__ bool value_direct(const uint8_t *img, uint32_t len, u
 template <typename E>
 __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_at(const uint8_t *__restrict__ src,
 							     const uint64_t *__restrict__ offsets, size_t n,
-							     size_t nblocks, const uint64_t *__restrict__ index,
-							     size_t m, typename E::S *__restrict__ dst)
+							     size_t nblocks, uint64_t stream_limit,
+							     const uint64_t *__restrict__ index, size_t m,
+							     typename E::S *__restrict__ dst)
 {
 	using C = typename E::C;
 	using S = typename E::S;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_at(const uint8_t *__rest
 	load_width_table(wt);
 	uint32_t *img = image[wave];
 	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
-	const uint64_t limit = uniform(offsets[nblocks]);
+	const uint64_t limit = min_u64(uniform(offsets[nblocks]), stream_limit);
 	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG * WAVE;
 	for (size_t q0 = (size_t(blockIdx.x) * WAVES_PER_WG + wave) * WAVE; q0 < m; q0 += stride) {
 		const size_t q = q0 + size_t(lane);
@@ -393,8 +394,11 @@ static unsigned walk_grid(size_t units)
 
 using namespace oroch_hip;
 
-extern "C" int oroch_group_find(int dtype, const void *src, const uint64_t *offsets, size_t n,
-				const uint64_t *values, size_t m, uint64_t *index, void *stream)
+// oroch_group_find and oroch_group_at with every block confined to the first
+// stream_bytes bytes of src (tables that come from a file or the network).
+int oroch_hip::group_find_within(int dtype, const void *src, const uint64_t *offsets, size_t n,
+				 const uint64_t *values, size_t m, uint64_t *index, uint64_t stream_bytes,
+				 void *stream)
 {
 	if (dtype < 0 || dtype > 7)
 		return OROCH_E_DTYPE;
@@ -414,19 +418,26 @@ extern "C" int oroch_group_find(int dtype, const void *src, const uint64_t *offs
 			if (!option(OROCH_OPT_FIND_ONE_BLOCK)) {
 				hipLaunchKernelGGL(k_find_quad<E>, dim3(walk_grid((nb + QUAD - 1) / QUAD)),
 						   dim3(WAVE * WAVES_PER_WG), 0, st, static_cast<const uint8_t *>(src),
-						   offsets, n, nb, values, m, reinterpret_cast<unsigned long long *>(index));
+						   offsets, n, nb, stream_bytes, values, m,
+						   reinterpret_cast<unsigned long long *>(index));
 				return int(hipGetLastError());
 			}
 		}
 		hipLaunchKernelGGL(k_find<E>, dim3(walk_grid(nb)), dim3(WAVE * WAVES_PER_WG), 0, st,
-				   static_cast<const uint8_t *>(src), offsets, n, nb, values, m,
+				   static_cast<const uint8_t *>(src), offsets, n, nb, stream_bytes, values, m,
 				   reinterpret_cast<unsigned long long *>(index));
 		return int(hipGetLastError());
 	});
 }
 
-extern "C" int oroch_group_at(int dtype, const void *src, const uint64_t *offsets, size_t n,
-			      const uint64_t *index, size_t m, void *dst, void *stream)
+extern "C" int oroch_group_find(int dtype, const void *src, const uint64_t *offsets, size_t n,
+				const uint64_t *values, size_t m, uint64_t *index, void *stream)
+{
+	return group_find_within(dtype, src, offsets, n, values, m, index, ~uint64_t(0), stream);
+}
+
+int oroch_hip::group_at_within(int dtype, const void *src, const uint64_t *offsets, size_t n,
+			       const uint64_t *index, size_t m, void *dst, uint64_t stream_bytes, void *stream)
 {
 	if (dtype < 0 || dtype > 7)
 		return OROCH_E_DTYPE;
@@ -439,10 +450,16 @@ extern "C" int oroch_group_at(int dtype, const void *src, const uint64_t *offset
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		hipLaunchKernelGGL(k_at<E>, dim3(walk_grid((m + WAVE - 1) / WAVE)), dim3(WAVE * WAVES_PER_WG), 0, st,
-				   static_cast<const uint8_t *>(src), offsets, n, nb, index, m,
+				   static_cast<const uint8_t *>(src), offsets, n, nb, stream_bytes, index, m,
 				   static_cast<typename E::S *>(dst));
 		return int(hipGetLastError());
 	});
+}
+
+extern "C" int oroch_group_at(int dtype, const void *src, const uint64_t *offsets, size_t n,
+			      const uint64_t *index, size_t m, void *dst, void *stream)
+{
+	return group_at_within(dtype, src, offsets, n, index, m, dst, ~uint64_t(0), stream);
 }
 
 // ---- the growable array -----------------------------------------------------------------
@@ -460,7 +477,7 @@ struct oroch_array
 	dev_buf stream;
 	size_t stream_cap = 0;   // bytes
 	dev_buf offsets;
-	size_t offsets_cap = 0;  // entries
+	size_t offsets_cap = 0;  // bytes
 	dev_buf small;           // needles, positions and results of one query batch
 	size_t small_cap = 0;    // bytes
 	std::vector<uint8_t> tail; // raw values not yet in a block
@@ -692,6 +709,8 @@ extern "C" int oroch_array_image(const oroch_array *a, uint64_t group, void *dst
 			       hipMemcpyDeviceToHost));
 	if (rc)
 		return rc;
+	if (ext[0] > ext[1] || ext[1] > a->stream_bytes)
+		return OROCH_E_ARGUMENT;
 	*bytes = ext[1] - ext[0];
 	if (*bytes > capacity)
 		return OROCH_E_CAPACITY;
@@ -779,23 +798,37 @@ static int load_array(oroch_array *a, const void *src_host, size_t bytes)
 	if (int(h.dtype) != a->dtype)
 		return OROCH_E_DTYPE;
 	const uint8_t *in = static_cast<const uint8_t *>(src_host);
-	const size_t nfull = size_t(h.nvalues / BLOCK), ntail = size_t(h.nvalues % BLOCK);
+	const size_t ntail = size_t(h.nvalues % BLOCK), nfull = size_t(h.nblocks) - (ntail ? 1 : 0);
 	const size_t w = a->width();
-	// the table may be anything: the images of the full groups must end inside
-	// the stream at a multiple of 16 for appends to go on from there
-	uint64_t full_bytes = 0;
+	// the table may be anything: every entry must be a multiple of 16 inside the
+	// stream and none lower than the one before, the first 0, for reads to stay
+	// inside the stream and appends to go on behind the last full group
+	const uint64_t *table = reinterpret_cast<const uint64_t *>(in + h.table_offset);
+	if ((size_t(h.nblocks) + 1) * sizeof(uint64_t) > h.stream_offset - h.table_offset ||
+	    !offsets_table_sound(table, size_t(h.nblocks) + 1, h.stream_bytes))
+		return OROCH_E_ARGUMENT;
+	uint64_t first_offset = 0, full_bytes = 0;
+	std::memcpy(&first_offset, table, sizeof first_offset);
 	std::memcpy(&full_bytes, in + h.table_offset + nfull * sizeof(uint64_t), sizeof full_bytes);
-	if (full_bytes > h.stream_bytes || (full_bytes & 15u) || (nfull == 0 && full_bytes != 0))
+	if (first_offset != 0)
 		return OROCH_E_ARGUMENT;
 	std::vector<uint8_t> tail(ntail * w);
 	if (ntail && (rc = oroch_container_decode_host(src_host, bytes, nfull, 1, tail.data())))
 		return rc;
 	if (nfull) {
-		if ((rc = grow(a->stream, a->stream_cap, size_t(full_bytes) + 16, 0)) ||
-		    (rc = grow(a->offsets, a->offsets_cap, (nfull + 1) * sizeof(uint64_t), 0)) ||
-		    (rc = staged_copy(a->stream.p, in + h.stream_offset, size_t(full_bytes), true, nullptr)) ||
-		    (rc = staged_copy(a->offsets.p, in + h.table_offset, (nfull + 1) * sizeof(uint64_t), true, nullptr)))
+		// into buffers of their own, which take the place of the array's only
+		// when both copies have arrived: a failure leaves the array as it was
+		dev_buf stream, offsets;
+		size_t stream_cap = 0, offsets_cap = 0;
+		if ((rc = grow(stream, stream_cap, size_t(full_bytes) + 16, 0)) ||
+		    (rc = grow(offsets, offsets_cap, (nfull + 1) * sizeof(uint64_t), 0)) ||
+		    (rc = staged_copy(stream.p, in + h.stream_offset, size_t(full_bytes), true, nullptr)) ||
+		    (rc = staged_copy(offsets.p, in + h.table_offset, (nfull + 1) * sizeof(uint64_t), true, nullptr)))
 			return rc;
+		a->stream.swap(stream);
+		a->stream_cap = stream_cap;
+		a->offsets.swap(offsets);
+		a->offsets_cap = offsets_cap;
 	}
 	a->nblocks = nfull;
 	a->stream_bytes = size_t(full_bytes);
@@ -828,8 +861,8 @@ extern "C" int oroch_array_find(oroch_array *a, const uint64_t *values, size_t m
 			return rc;
 		uint64_t *d_values = static_cast<uint64_t *>(a->small.p), *d_index = d_values + m;
 		if ((rc = int(hipMemcpy(d_values, values, m * sizeof(uint64_t), hipMemcpyHostToDevice))) ||
-		    (rc = oroch_group_find(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p),
-					   a->in_blocks(), d_values, m, d_index, nullptr)) ||
+		    (rc = group_find_within(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p),
+					    a->in_blocks(), d_values, m, d_index, a->stream_bytes, nullptr)) ||
 		    (rc = int(hipMemcpy(index, d_index, m * sizeof(uint64_t), hipMemcpyDeviceToHost))))
 			return rc;
 	}
@@ -868,8 +901,8 @@ extern "C" int oroch_array_at(oroch_array *a, const uint64_t *index, size_t m, v
 		uint64_t *d_index = static_cast<uint64_t *>(a->small.p);
 		void *d_out = static_cast<uint8_t *>(a->small.p) + ibytes;
 		if ((rc = int(hipMemcpy(d_index, index, ibytes, hipMemcpyHostToDevice))) ||
-		    (rc = oroch_group_at(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p),
-					 a->in_blocks(), d_index, m, d_out, nullptr)) ||
+		    (rc = group_at_within(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p),
+					  a->in_blocks(), d_index, m, d_out, a->stream_bytes, nullptr)) ||
 		    (rc = int(hipMemcpy(dst_host, d_out, m * w, hipMemcpyDeviceToHost))))
 			return rc;
 	}
@@ -897,8 +930,8 @@ extern "C" int oroch_array_read(oroch_array *a, uint64_t first, uint64_t count, 
 		dev_buf vals;
 		int rc;
 		if ((rc = vals.alloc(nv * w)) ||
-		    (rc = oroch_group_decode(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p) + b0,
-					     nv, vals.p, nullptr)) ||
+		    (rc = group_decode_within(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p) + b0,
+					      nv, vals.p, a->stream_bytes, nullptr)) ||
 		    (rc = staged_copy(out, static_cast<uint8_t *>(vals.p) + (first - b0 * BLOCK) * w,
 				      (bstop - first) * w, false, nullptr)))
 			return rc;
@@ -934,8 +967,8 @@ static int insert_value(oroch_array *a, uint64_t index, uint64_t value)
 	dev_buf vals, moved;
 	uint64_t cut = 0;
 	if ((rc = vals.alloc(cnt * w)) || (rc = moved.alloc((cnt + 1) * w)) ||
-	    (rc = oroch_group_decode(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p) + g, cnt,
-				     vals.p, nullptr)) ||
+	    (rc = group_decode_within(a->dtype, a->stream.p, static_cast<const uint64_t *>(a->offsets.p) + g, cnt,
+				      vals.p, a->stream_bytes, nullptr)) ||
 	    (rc = int(hipMemcpy(&cut, static_cast<const uint64_t *>(a->offsets.p) + g, sizeof(cut),
 				hipMemcpyDeviceToHost))))
 		return rc;

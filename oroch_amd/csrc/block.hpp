@@ -379,7 +379,7 @@ constexpr int WALK_SKIP = 0, WALK_DECODE = 1, WALK_STOP = -1;
 template <typename E, typename Want, typename Sink>
 __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 					     const uint64_t *__restrict__ offsets, size_t n,
-					     size_t nblocks, Want want, Sink sink)
+					     size_t nblocks, uint64_t stream_limit, Want want, Sink sink)
 {
 	using C = typename E::C;
 	constexpr uint32_t MAXLEN = uint32_t(image_bytes<E>() - 16);
@@ -409,9 +409,11 @@ __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 		}
 	};
 	// Offsets come from the caller's table and may be anything: every block is
-	// confined to [0, offsets[nblocks]), the length of the stream, so a damaged
-	// table yields wrong values but no read outside the stream.
-	const uint64_t limit = uniform(offsets[nblocks]);
+	// confined to [0, offsets[nblocks]), the length of the stream, and to the
+	// stream_limit of the caller (the size of the memory behind src when the
+	// table comes from a file or the network), so a damaged table yields wrong
+	// values but no read outside the stream.
+	const uint64_t limit = min_u64(uniform(offsets[nblocks]), stream_limit);
 	auto resolve = [&](uint64_t &off, uint64_t end, uint32_t &len) {
 		// lane 0 holds offsets[blk], lane 1 offsets[blk + 1]
 		const uint64_t o = min_u64(read_lane(off, 0), limit) & ~uint64_t(15);

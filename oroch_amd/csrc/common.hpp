@@ -117,6 +117,20 @@ struct no_profile_scope
 // current device, looked up on the first call per device; group.hip.
 int static_scratch_setup(void **ptr);
 
+// oroch_group_decode / _find / _at for a table that is not trusted (read from a
+// file or the network): every block stays inside the first stream_bytes bytes
+// of src whatever the table says.  group.hip, array.hip.
+int group_decode_within(int dtype, const void *src, const uint64_t *offsets, size_t n, void *dst,
+			uint64_t stream_bytes, void *stream);
+int group_find_within(int dtype, const void *src, const uint64_t *offsets, size_t n, const uint64_t *values,
+		      size_t m, uint64_t *index, uint64_t stream_bytes, void *stream);
+int group_at_within(int dtype, const void *src, const uint64_t *offsets, size_t n, const uint64_t *index,
+		    size_t m, void *dst, uint64_t stream_bytes, void *stream);
+
+// Host-side check of a table of block offsets read from outside: rising,
+// multiples of 16, none beyond stream_bytes.
+bool offsets_table_sound(const uint64_t *table, size_t entries, uint64_t stream_bytes);
+
 #ifdef __HIPCC__
 
 __constant__ const width_table g_width = make_width_table();

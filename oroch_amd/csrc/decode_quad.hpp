@@ -373,7 +373,7 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 template <typename E, typename Want, typename Sink>
 __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 					    const uint64_t *__restrict__ offsets, size_t n, size_t nblocks,
-					    Want want, Sink sink)
+					    uint64_t stream_limit, Want want, Sink sink)
 {
 	using C = typename E::C;
 	constexpr uint32_t IMG = uint32_t(image_bytes<E>() - 16); // longest block image
@@ -406,9 +406,10 @@ __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 		}
 	};
 	// Offsets come from the caller's table and may be anything: the quad is
-	// confined to [0, offsets[nblocks]), the length of the stream, so a damaged
-	// table yields wrong values but no read outside the stream.
-	const uint64_t limit = uniform(offsets[nblocks]);
+	// confined to [0, offsets[nblocks]), the length of the stream, and to the
+	// caller's stream_limit, so a damaged table yields wrong values but no read
+	// outside the stream.
+	const uint64_t limit = min_u64(uniform(offsets[nblocks]), stream_limit);
 	auto resolve = [&](uint64_t o, uint64_t &start, uint32_t &rel, uint32_t &total) {
 		start = min_u64(read_lane(o, 0), limit) & ~uint64_t(15);
 		const uint64_t room = limit - start;
@@ -493,11 +494,11 @@ __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 template <typename E>
 __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_decode_quad(
 	const uint8_t *__restrict__ src, const uint64_t *__restrict__ offsets, size_t n, size_t nblocks,
-	typename E::S *__restrict__ dst)
+	uint64_t stream_limit, typename E::S *__restrict__ dst)
 {
 	using C = typename E::C;
 	walk_quads<E>(
-		src, offsets, n, nblocks, [](size_t) { return WALK_DECODE; },
+		src, offsets, n, nblocks, stream_limit, [](size_t) { return WALK_DECODE; },
 		[&](size_t blk, int nv, int lane, const C(&v)[VPL]) { store_block<E>(dst, blk * BLOCK, nv, lane, v); });
 }
 

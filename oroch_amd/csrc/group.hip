@@ -1016,13 +1016,13 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_stats(const typename E::
 template <typename E>
 __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_decode(const uint8_t *__restrict__ src,
 								 const uint64_t *__restrict__ offsets,
-								 size_t n, size_t nblocks,
+								 size_t n, size_t nblocks, uint64_t stream_limit,
 								 typename E::S *__restrict__ dst)
 {
 	using C = typename E::C;
 	const int lane = lane_id();
 	walk_blocks<E>(
-		src, offsets, n, nblocks, [](size_t, const uint32_t *, uint32_t) { return WALK_DECODE; },
+		src, offsets, n, nblocks, stream_limit, [](size_t, const uint32_t *, uint32_t) { return WALK_DECODE; },
 		[&](size_t blk, int nv, const C(&v)[VPL]) { store_block<E>(dst, blk * BLOCK, nv, lane, v); });
 }
 
@@ -1476,8 +1476,11 @@ extern "C" int oroch_group_encode_static(int dtype, const void *src, size_t n, v
 				 stream);
 }
 
-extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n,
-				  void *dst, void *stream)
+// Decodes with every block confined to the first stream_bytes bytes of src (and
+// to offsets[nblocks], as always): for tables that come from a file or the
+// network.
+int oroch_hip::group_decode_within(int dtype, const void *src, const uint64_t *offsets, size_t n, void *dst,
+				   uint64_t stream_bytes, void *stream)
 {
 	if (dtype < 0 || dtype > 7)
 		return OROCH_E_DTYPE;
@@ -1505,14 +1508,20 @@ extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *of
 				unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
 				qgrid = qgrid < 16384u ? qgrid : 16384u;
 				hipLaunchKernelGGL(k_decode_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
-						   static_cast<const uint8_t *>(src), offsets, n, nb,
+						   static_cast<const uint8_t *>(src), offsets, n, nb, stream_bytes,
 						   static_cast<typename E::S *>(dst));
 				return int(hipGetLastError());
 			}
 		}
 		hipLaunchKernelGGL(k_decode<E>, dim3(grid), dim3(WAVE * WAVES_PER_WG), 0, st,
-				   static_cast<const uint8_t *>(src), offsets, n, nb,
+				   static_cast<const uint8_t *>(src), offsets, n, nb, stream_bytes,
 				   static_cast<typename E::S *>(dst));
 		return int(hipGetLastError());
 	});
+}
+
+extern "C" int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size_t n,
+				  void *dst, void *stream)
+{
+	return group_decode_within(dtype, src, offsets, n, dst, ~uint64_t(0), stream);
 }

@@ -448,6 +448,61 @@ def test_damaged_streams_stay_inside_the_stream(hip, dt):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("dt", [np.int16, np.int32, np.int64])
+def test_damaged_container_tables(hip, dt):
+    """The offsets table of a container comes from a file or the network.  With
+    the table in host memory a damaged entry is an error; with the container in
+    device memory the decoder keeps every block inside the stream, so entries
+    far beyond it (which would otherwise be a GPU fault) give wrong values at
+    most; an array does not load a container with a damaged table."""
+    import torch
+
+    rng = np.random.default_rng(17)
+    a = np.concatenate([dg.fuzz_block(rng, dt, 256) for _ in range(40)] + [dg.fuzz_block(rng, dt, 100)])
+    good = hip.container_encode_host(a)
+    h = good[:64].view(hip.capi.HEADER_DTYPE)[0]
+    nb, stream_bytes = int(h["nblocks"]), int(h["stream_bytes"])
+
+    def damaged(entry, value):
+        c = good.copy()
+        c[64:64 + 8 * (nb + 1)].view(np.uint64)[entry] = np.uint64(value)
+        return c
+
+    cases = [(nb, 1 << 40), (nb, stream_bytes + 16), (7, 1 << 40), (7, 8), (12, 0), (nb - 1, 1 << 62), (0, 16)]
+    for entry, value in cases:
+        c = damaged(entry, value)
+        with pytest.raises(hip.OrochError):
+            hip.container_decode_host(c)
+        arr = hip.IntegerArray(dt)
+        arr.append(a[:300])
+        with pytest.raises(hip.OrochError):
+            arr.load(c)
+        # the array is as it was
+        assert len(arr) == 300 and np.array_equal(arr.read(0, 300), a[:300])
+        # on the device nobody has looked at the table: no fault, and the blocks
+        # whose entries (and those of the three they may share a wavefront with) are
+        # intact come out right
+        d = torch.from_numpy(c).cuda()
+        got = host(hip.container_decode(d)).view(dt)
+        torch.cuda.synchronize()
+        assert got.size == a.size
+        for b in range(nb):
+            # the four-block decoder takes the extents of four blocks together
+            if not 4 * (b // 4) <= entry <= 4 * (b // 4) + 4 and entry != nb:
+                assert np.array_equal(got[b * 256:(b + 1) * 256], a[b * 256:(b + 1) * 256]), (entry, value, b)
+        # a range that ends at the damaged entry: it is the limit the kernel reads
+        if 0 < entry < nb:
+            hip.container_decode(d, 0, entry)
+            torch.cuda.synchronize()
+    # blocks that do not touch the damaged entry decode through the host path too
+    c = damaged(20, 1 << 40)
+    assert np.array_equal(hip.container_decode_host(c, 0, 19), a[:19 * 256])
+    assert np.array_equal(hip.container_decode_host(c, 21, nb - 21), a[21 * 256:])
+    arr = hip.IntegerArray(dt)
+    arr.load(good)
+    assert len(arr) == a.size and np.array_equal(arr.read(0, a.size), a)
+
+
 @pytest.mark.parametrize("dt", [np.uint8, np.int16, np.uint32, np.int64])
 def test_batched_fetch(hip, oracle, dt):
     """Random access into packed sequences (bitpck.h:258-266, bitfor.h:71-74)."""
