@@ -105,17 +105,21 @@ def cpu_baseline(log2n, seed):
                       "(encode %.2fs, decode %.2fs)" % (log2n, t1 - t0, t2 - t1)}
 
 
-def measured_traffic(kernel, log2n):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3
-    cannot run inside this process); only valid for the workload they were
-    collected on."""
+def measured_traffic(direction, log2n):
+    """HBM bytes per step of one direction ("encode": every kernel of the
+    encode path, "decode": the decode kernel) from the committed PMC passes
+    (rocprofv3 cannot run inside this process), and the commit whose kernels
+    were measured; only valid for the workload they were collected on."""
     path = os.path.join(ROOT, "profiles", "traffic_int32_2p30.json")
     if log2n != 30 or not os.path.exists(path):
-        return None
-    k = json.load(open(path)).get("kernels", {})
-    names = {"select": "k_select_quad", "encode": "k_encode_quad", "decode": "k_decode_quad"}
-    rec = k.get(names.get(kernel, ""))
-    return rec["total_bytes"] if rec else None
+        return None, None
+    rec = json.load(open(path))
+    k = rec.get("kernels", {})
+    if not k:
+        return None, None
+    decode = sum(v["total_bytes"] for name, v in k.items() if "decode" in name)
+    encode = sum(v["total_bytes"] for name, v in k.items() if "decode" not in name)
+    return (decode if direction == "decode" else encode), rec.get("commit")
 
 
 def end_to_end(x_dev, log2n):
@@ -168,8 +172,8 @@ def end_to_end(x_dev, log2n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=30, help="log2 of values per GPU")
     ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -272,9 +276,19 @@ def main():
         # algorithmic HBM bytes per launch: encode side reads the values once and
         # writes the stream; decode reads the stream and writes the values
         algo = {"select": raw, "encode": raw + total, "decode": raw + total, "scan": 0}
-        dominant = max((k for k in kern if k in ("select", "encode", "decode")), key=lambda k: kern[k])
-        achieved = algo[dominant] / (kern[dominant] * 1e-3) / 1e9
         enc_path_ms = sum(kern.get(k, 0.0) for k in ("select", "scan", "encode"))
+        dec_path_ms = kern.get("decode", 0.0)
+        paths = {
+            "encode": {"ms": enc_path_ms, "algorithmic_bytes": raw + total,
+                       "kernels": [k for k in ("select", "scan", "encode") if k in kern]},
+            "decode": {"ms": dec_path_ms, "algorithmic_bytes": raw + total, "kernels": ["decode"]},
+        }
+        for d, p in paths.items():
+            p["achieved"] = p["algorithmic_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] else 0.0
+            p["frac"] = p["achieved"] / HBM_PEAK_GBS
+            p["traffic"], p["traffic_commit"] = measured_traffic(d, args.log2n)
+        # the figure of merit is the slower direction
+        worse = min(paths, key=lambda d: paths[d]["frac"])
         line = {
             "metric": "device-resident encode+decode GB/s (uncompressed bytes), per-block bitpfr int32",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
@@ -289,14 +303,13 @@ def main():
                        "no data-path collective" % world},
             "encode_GBps": raw / (enc_ms * 1e-3) / 1e9, "decode_GBps": raw / (dec_ms * 1e-3) / 1e9,
             "kernel_ms": kern,
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(dominant, args.log2n),
-                         "algorithmic_bytes_per_launch": algo[dominant],
-                         "encode_path": {"ms": enc_path_ms, "algorithmic_bytes": raw + total,
-                                         "frac": (raw + total) / (enc_path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         "decode_path": {"ms": kern.get("decode", 0.0), "algorithmic_bytes": raw + total,
-                                         "frac": (raw + total) / (kern.get("decode", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "roofline": {"bound": "hbm", "kernel": "%s direction (%s)" % (worse, "+".join(paths[worse]["kernels"])),
+                         "achieved": paths[worse]["achieved"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": paths[worse]["frac"],
+                         "traffic": paths[worse]["traffic"],
+                         "traffic_commit": paths[worse]["traffic_commit"],
+                         "algorithmic_bytes_per_launch": paths[worse]["algorithmic_bytes"],
+                         "encode_path": paths["encode"], "decode_path": paths["decode"]},
             "shard_bytes": counts,
         }
         if world == 1 and not args.no_end_to_end:

@@ -35,3 +35,6 @@ def test_bench_prints_one_complete_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+    # the figure of merit is the slower of the two directions
+    assert abs(r["frac"] - min(r["encode_path"]["frac"], r["decode_path"]["frac"])) < 1e-9
+    assert r["kernel"].split()[0] in ("encode", "decode")
