@@ -1,6 +1,7 @@
 // bitfor.h -- bit packing with a frame of reference.
 // Stands in for /root/reference/oroch/bitfor.h:36-71: bitpck_codec with
 // origin_codec as the value codec.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_BITFOR_H_
 #define OROCH_BITFOR_H_
 
@@ -15,12 +16,15 @@ class bitfor_codec
 public:
 	using original_t = T;
 
+	// The value codec of the packed words: subtracts the frame's origin
+	// (origin.h), and carries the width along for the codec's callers.
 	struct parameters : public origin_codec<original_t>
 	{
-		parameters(original_t f, size_t n) : origin_codec<original_t>(f), nbits(n)
+		const size_t nbits;
+
+		parameters(original_t frame, size_t width) : origin_codec<original_t>(frame), nbits(width)
 		{
 		}
-		const size_t nbits;
 	};
 
 	using basic_codec = bitpck_codec<original_t, parameters>;
@@ -29,20 +33,23 @@ public:
 	{
 		return basic_codec::space(nvalues, nbits);
 	}
+
+	// bitfor.h:59-69: the width and the origin both come from `p`.
 	template <typename Iter>
-	static void encode(dst_bytes_t &dst, Iter src, Iter const end, const parameters &params)
+	static void encode(dst_bytes_t &dst, Iter src, Iter const end, const parameters &p)
 	{
-		basic_codec::encode(dst, src, end, params.nbits, params);
+		basic_codec::encode(dst, src, end, p.nbits, p);
 	}
 	template <typename Iter>
-	static void decode(Iter dst, Iter const end, src_bytes_t &src, const parameters &params)
+	static void decode(Iter dst, Iter const end, src_bytes_t &src, const parameters &p)
 	{
-		basic_codec::decode(dst, end, src, params.nbits, params);
+		basic_codec::decode(dst, end, src, p.nbits, p);
 	}
-	// bitfor.h:71-74.
-	static original_t fetch(src_bytes_t src, size_t index, const parameters &params)
+
+	// bitfor.h:71-74: one value, without unpacking its neighbours.
+	static original_t fetch(src_bytes_t src, size_t index, const parameters &p)
 	{
-		return basic_codec::fetch(src, index, params.nbits, params);
+		return basic_codec::fetch(src, index, p.nbits, p);
 	}
 };
 

@@ -9,6 +9,7 @@
 // The value codec is fused into the kernels, so only the two the block path
 // uses are accepted: zigzag_codec<T> (the default) and origin_codec<T> or a
 // class derived from it.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_BITPCK_H_
 #define OROCH_BITPCK_H_
 
@@ -110,10 +111,13 @@ public:
 	static original_t block_fetch(src_bytes_t src, const size_t index, const size_t nbits,
 				      value_codec &vcodec)
 	{
-		std::vector<T> out(index + 1);
-		src_bytes_t s = src;
-		decode(out.begin(), out.end(), s, nbits, vcodec);
-		return out[index];
+		using kind = detail::value_codec_kind<T, V>;
+		const uint64_t at = index;
+		T out = T();
+		hip::check(oroch_bitpck_fetch_host(hip::dtype_of<T>(), kind::kind, src, kind::origin(vcodec),
+						   unsigned(nbits), &at, 1, &out),
+			   "bitpck_codec::block_fetch");
+		return out;
 	}
 
 	// bitpck.h:258-266: value `index` of a packed sequence.

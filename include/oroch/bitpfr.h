@@ -6,6 +6,7 @@
 // packing; here one device pass packs, a second one finds the exceptions and
 // writes both lists in sequence order (gap-coded positions as
 // offset_codec<size_t, 1, false> produces them, and the high parts).
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_BITPFR_H_
 #define OROCH_BITPFR_H_
 

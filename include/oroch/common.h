@@ -1,5 +1,6 @@
 // common.h -- byte and pointer types shared by every codec signature.
 // Stands in for /root/reference/oroch/common.h:29-35.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_COMMON_H_
 #define OROCH_COMMON_H_
 

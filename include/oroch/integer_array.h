@@ -9,6 +9,7 @@
 // a loop over the array there is one device pass here, and the bulk forms
 // (append, find and at over many values, read) are added for callers that have
 // more than one value at hand.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_INTEGER_ARRAY_H_
 #define OROCH_INTEGER_ARRAY_H_
 

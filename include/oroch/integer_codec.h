@@ -3,12 +3,16 @@
 // Stands in for /root/reference/oroch/integer_codec.h:46-610.
 //
 // encoding_t, the descriptors and the metadata byte format are host code: a
-// few bytes per block.  select / encode / decode hand one block (at most
-// OROCH_BLOCK_VALUES values) to the HIP library; longer sequences are the
-// business of the batch entry points (oroch_group_encode and friends, or
-// integer_blocks<T> in integer_group.h), which is also where throughput
-// comes from -- these per-block calls pay a PCIe round trip each and exist so
-// that code written against the reference keeps working unchanged.
+// few bytes per group.  select / encode / decode hand the range they are given
+// to the HIP library as ONE group, whatever its length: up to
+// OROCH_BLOCK_VALUES values go through the block kernels (one wavefront),
+// longer ranges through the whole-sequence kernels (oroch_sequence_*).  encode
+// codes the values the way the metadata it is handed says, whoever made it.
+// Throughput comes from the batch entry points (oroch_group_encode and
+// friends, or integer_blocks<T> in integer_group.h) -- these per-group calls pay
+// a PCIe round trip each and exist so that code written against the reference
+// keeps working unchanged.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_INTEGER_CODEC_H_
 #define OROCH_INTEGER_CODEC_H_
 
@@ -216,20 +220,69 @@ inline void from_record(encoding_metadata<T> &meta, const oroch_block_desc &r)
 	}
 }
 
+// encoding_metadata<T> <-> the descriptor of the whole-sequence entry points.
+template <typename T>
+inline void from_record(encoding_metadata<T> &meta, const oroch_sequence_desc &r)
+{
+	using unsigned_t = typename integer_traits<T>::unsigned_t;
+	meta.clear();
+	meta.value_desc.encoding = static_cast<encoding_t>(r.encoding);
+	meta.value_desc.dataspace = size_t(r.dataspace);
+	meta.value_desc.metaspace = size_t(r.metaspace) - 1;
+	meta.value_desc.origin = static_cast<T>(static_cast<unsigned_t>(r.origin));
+	meta.value_desc.nbits = r.nbits;
+	if (r.encoding == bitpfr) {
+		meta.noutliers = size_t(r.noutliers);
+		meta.outlier_index_desc.encoding = static_cast<encoding_t>(r.index_encoding);
+		meta.outlier_index_desc.nbits = r.index_nbits;
+		meta.outlier_value_desc.encoding = static_cast<encoding_t>(r.value_encoding);
+		meta.outlier_value_desc.nbits = r.value_nbits;
+	}
+}
+
+template <typename T>
+inline oroch_sequence_desc to_record(const encoding_metadata<T> &meta, size_t n)
+{
+	using unsigned_t = typename integer_traits<T>::unsigned_t;
+	oroch_sequence_desc r;
+	std::memset(&r, 0, sizeof r);
+	r.encoding = byte_t(meta.value_desc.encoding);
+	r.origin = uint64_t(static_cast<unsigned_t>(meta.value_desc.origin));
+	r.nbits = byte_t(meta.value_desc.nbits);
+	r.dataspace = meta.value_desc.dataspace;
+	r.metaspace = uint32_t(meta.metaspace());
+	r.nvalues = n;
+	r.noutliers = meta.noutliers;
+	r.index_encoding = byte_t(meta.outlier_index_desc.encoding);
+	r.index_nbits = byte_t(meta.outlier_index_desc.nbits);
+	r.value_encoding = byte_t(meta.outlier_value_desc.encoding);
+	r.value_nbits = byte_t(meta.outlier_value_desc.nbits);
+	return r;
+}
+
+// Whether two metadata objects say the same about how values are coded.
+template <typename T>
+inline bool same_coding(const encoding_metadata<T> &a, const encoding_metadata<T> &b)
+{
+	const encoding_t e = a.value_desc.encoding;
+	if (e != b.value_desc.encoding)
+		return false;
+	if ((e == naught || e == varfor || e == bitfor || e == bitpfr) && a.value_desc.origin != b.value_desc.origin)
+		return false;
+	if ((e == bitpck || e == bitfor || e == bitpfr) && a.value_desc.nbits != b.value_desc.nbits)
+		return false;
+	if (e != bitpfr)
+		return true;
+	const bool ia = a.outlier_index_desc.encoding == bitpck, ib = b.outlier_index_desc.encoding == bitpck;
+	const bool va = a.outlier_value_desc.encoding == bitpck, vb = b.outlier_value_desc.encoding == bitpck;
+	return a.noutliers == b.noutliers && ia == ib && va == vb
+	       && (!ia || a.outlier_index_desc.nbits == b.outlier_index_desc.nbits)
+	       && (!va || a.outlier_value_desc.nbits == b.outlier_value_desc.nbits);
+}
+
 inline size_t align8(size_t x)
 {
 	return (x + 7) & ~size_t(7);
-}
-
-template <typename T, typename Iter>
-inline std::vector<T> gather_block(const char *what, Iter src, Iter const end)
-{
-	std::vector<T> in = hip::gather<T>(src, end);
-	if (in.size() > OROCH_BLOCK_VALUES)
-		throw std::length_error(std::string(what)
-					+ ": one call takes one block of at most 256 values; "
-					  "use the batch entry points for longer sequences");
-	return in;
 }
 
 } // namespace detail
@@ -247,47 +300,64 @@ public:
 	template <typename Iter>
 	static void select(metadata &meta, Iter const src, Iter const end)
 	{
-		const std::vector<T> in = detail::gather_block<T>("integer_codec::select", src, end);
+		const std::vector<T> in = hip::gather<T>(src, end);
 		if (in.empty()) {
 			meta.clear();
 			return;
 		}
-		oroch_block_desc rec;
-		hip::check(oroch_group_select_host(hip::dtype_of<T>(), in.data(), in.size(), &rec),
+		if (in.size() <= OROCH_BLOCK_VALUES) {
+			oroch_block_desc rec;
+			hip::check(oroch_group_select_host(hip::dtype_of<T>(), in.data(), in.size(), &rec),
+				   "integer_codec::select");
+			detail::from_record(meta, rec);
+			return;
+		}
+		oroch_sequence_desc rec;
+		hip::check(oroch_sequence_select_host(hip::dtype_of<T>(), in.data(), in.size(), &rec),
 			   "integer_codec::select");
 		detail::from_record(meta, rec);
 	}
 
-	// integer_codec.h:386-393.  The device selects and encodes in one
-	// pass; meta has to be what select() returns for the same values.
+	// integer_codec.h:386-393.  A block whose metadata is what select()
+	// makes of it takes the fused block kernel (one launch selects and
+	// encodes); any other metadata, and any longer range, is coded as the
+	// metadata says by the whole-sequence kernels.
 	template <typename Iter>
 	static void encode(dst_bytes_t &dst, Iter src, Iter const end, metadata &meta)
 	{
-		const std::vector<T> in = detail::gather_block<T>("integer_codec::encode", src, end);
+		const std::vector<T> in = hip::gather<T>(src, end);
 		if (in.empty())
 			return;
-		std::vector<byte_t> image(oroch_group_bound(hip::dtype_of<T>(), in.size()));
-		uint64_t offsets[2], total = 0;
-		hip::check(oroch_group_encode_host(hip::dtype_of<T>(), in.data(), in.size(), image.data(),
-						   image.size(), offsets, &total),
+		if (in.size() <= OROCH_BLOCK_VALUES) {
+			std::vector<byte_t> image(oroch_group_bound(hip::dtype_of<T>(), in.size()));
+			uint64_t offsets[2], total = 0;
+			hip::check(oroch_group_encode_host(hip::dtype_of<T>(), in.data(), in.size(), image.data(),
+							   image.size(), offsets, &total),
+				   "integer_codec::encode");
+			metadata made;
+			src_bytes_t p = image.data();
+			made.decode(p);
+			if (detail::same_coding(made, meta)) {
+				const size_t at = detail::align8(size_t(p - image.data()));
+				const size_t bytes = detail::data_extent(made, in.size(), image.data() + at);
+				std::memcpy(dst, image.data() + at, bytes);
+				dst += bytes;
+				return;
+			}
+		}
+		const oroch_sequence_desc rec = detail::to_record(meta, in.size());
+		// room for what this metadata can produce: packed words, two lists of
+		// varints at their longest, or one varint per value at its longest
+		const size_t w = sizeof(T), longest = (8 * w + 6) / 7;
+		size_t room = in.size() * (w > longest ? w : longest) + 16;
+		if (rec.encoding == bitpfr)
+			room = oroch_bitpck_space(in.size(), rec.nbits ? rec.nbits : 1) + size_t(rec.noutliers) * 20 + 48;
+		std::vector<byte_t> data(room);
+		uint64_t bytes = 0;
+		hip::check(oroch_sequence_encode_host(hip::dtype_of<T>(), in.data(), in.size(), &rec, data.data(),
+						      data.size(), &bytes),
 			   "integer_codec::encode");
-		metadata made;
-		src_bytes_t p = image.data();
-		made.decode(p);
-		const auto &a = made.value_desc;
-		const auto &b = meta.value_desc;
-		bool same = a.encoding == b.encoding;
-		if (same && (a.encoding == naught || a.encoding == varfor || a.encoding == bitfor
-			     || a.encoding == bitpfr))
-			same = a.origin == b.origin;
-		if (same && (a.encoding == bitpck || a.encoding == bitfor || a.encoding == bitpfr))
-			same = a.nbits == b.nbits;
-		if (!same)
-			throw std::logic_error("integer_codec::encode: metadata does not come from select() "
-					       "on these values");
-		const size_t at = detail::align8(size_t(p - image.data()));
-		const size_t bytes = meta.dataspace();
-		std::memcpy(dst, image.data() + at, bytes);
+		std::memcpy(dst, data.data(), size_t(bytes));
 		dst += bytes;
 	}
 
@@ -298,21 +368,25 @@ public:
 		const size_t n = size_t(std::distance(dst, end));
 		if (n == 0)
 			return;
-		if (n > OROCH_BLOCK_VALUES)
-			throw std::length_error("integer_codec::decode: one call takes one block of at most "
-						"256 values; use the batch entry points for longer sequences");
 		const size_t bytes = detail::data_extent(meta, n, src);
-		byte_t head[48] = {};
-		dst_bytes_t h = head;
-		meta.encode(h);
-		const size_t at = detail::align8(size_t(h - head));
-		std::vector<byte_t> image(((at + bytes + 15) & ~size_t(15)) + 16);
-		std::memcpy(image.data(), head, at);
-		std::memcpy(image.data() + at, src, bytes);
-		const uint64_t offsets[2] = {0, (at + bytes + 15) & ~uint64_t(15)};
 		std::vector<T> out(n);
-		hip::check(oroch_group_decode_host(hip::dtype_of<T>(), image.data(), offsets, n, out.data()),
-			   "integer_codec::decode");
+		if (n <= OROCH_BLOCK_VALUES) {
+			byte_t head[48] = {};
+			dst_bytes_t h = head;
+			meta.encode(h);
+			const size_t at = detail::align8(size_t(h - head));
+			std::vector<byte_t> image(((at + bytes + 15) & ~size_t(15)) + 16);
+			std::memcpy(image.data(), head, at);
+			std::memcpy(image.data() + at, src, bytes);
+			const uint64_t offsets[2] = {0, (at + bytes + 15) & ~uint64_t(15)};
+			hip::check(oroch_group_decode_host(hip::dtype_of<T>(), image.data(), offsets, n, out.data()),
+				   "integer_codec::decode");
+		} else {
+			const oroch_sequence_desc rec = detail::to_record(meta, n);
+			hip::check(oroch_sequence_decode_host(hip::dtype_of<T>(), src, bytes, n, &rec, out.data(),
+							      nullptr),
+				   "integer_codec::decode");
+		}
 		std::copy(out.begin(), out.end(), dst);
 		src += bytes;
 	}

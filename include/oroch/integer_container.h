@@ -4,6 +4,7 @@
 // serialised form); the layout is described in oroch_hip.h.  Every block image
 // inside is byte-identical to integer_group<T>::encode(aligned = true), and any
 // range of blocks can be decoded without the rest.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_INTEGER_CONTAINER_H_
 #define OROCH_INTEGER_CONTAINER_H_
 

@@ -2,11 +2,13 @@
 // the GPU path is built around.
 // Stands in for /root/reference/oroch/integer_group.h:34-86.
 //
-// integer_group<T> keeps the reference's class: one block of at most
-// OROCH_BLOCK_VALUES values, image = [metadata][zero pad to 8][data].
-// integer_blocks<T> is the same thing for a whole array at once -- what the
-// reference's callers write as a loop over a vector of integer_group
-// (tests/bench/group-bench.cc:50-75) is one device pass here.
+// integer_group<T> keeps the reference's class: one group of any number of
+// values, image = [metadata][zero pad to 8][data]; up to OROCH_BLOCK_VALUES
+// values take one launch of the block kernels, longer groups the
+// whole-sequence kernels.  integer_blocks<T> is a whole array cut into blocks
+// of OROCH_BLOCK_VALUES, all coded by one device pass -- what the reference's
+// callers write as a loop over a vector of integer_group
+// (tests/bench/group-bench.cc:50-75).
 #ifndef OROCH_INTEGER_GROUP_H_
 #define OROCH_INTEGER_GROUP_H_
 
@@ -31,12 +33,16 @@ public:
 	template <typename Iter>
 	void encode(Iter begin, Iter const end, bool aligned = true)
 	{
-		const std::vector<T> in = detail::gather_block<T>("integer_group::encode", begin, end);
+		const std::vector<T> in = hip::gather<T>(begin, end);
 		if (in.empty()) {
 			// integer_codec.h:248-253: normal encoding, no data.
 			size_ = aligned ? alignment : 1;
 			data_.reset(new byte_t[size_]());
 			data_[0] = encoding_t::normal;
+			return;
+		}
+		if (in.size() > OROCH_BLOCK_VALUES) {
+			encode_long(in, aligned);
 			return;
 		}
 		std::vector<byte_t> image(oroch_group_bound(hip::dtype_of<T>(), in.size()));
@@ -57,28 +63,23 @@ public:
 		std::memcpy(data_.get() + offset, image.data() + at, bytes);
 	}
 
-	// integer_group.h:62-76.
+	// integer_group.h:62-76: the metadata says where the data starts.
 	template <typename Iter>
 	void decode(Iter begin, Iter const end, bool aligned = true) const
 	{
 		typename codec::metadata meta;
-		src_bytes_t meta_bytes = data_.get();
-		src_bytes_t meta_start = meta_bytes;
-		meta.decode(meta_bytes);
-
-		size_t offset = size_t(meta_bytes - meta_start);
-		if (aligned)
-			offset = (offset + alignment_mask) & ~alignment_mask;
-
-		src_bytes_t data_bytes = data_.get() + offset;
-		codec::decode(begin, end, data_bytes, meta);
+		src_bytes_t cursor = data_.get();
+		meta.decode(cursor);
+		const size_t head = size_t(cursor - data_.get());
+		src_bytes_t body = data_.get() + (aligned ? detail::align8(head) : head);
+		codec::decode(begin, end, body, meta);
 	}
 
-	// integer_group.h:78-82.
+	// integer_group.h:78-82: the metadata alone.
 	void decode(typename codec::metadata &meta) const
 	{
-		src_bytes_t meta_bytes = data_.get();
-		meta.decode(meta_bytes);
+		src_bytes_t cursor = data_.get();
+		meta.decode(cursor);
 	}
 
 	// Not in the reference: the image and its length, for tests and for
@@ -93,6 +94,28 @@ public:
 	}
 
 protected:
+	// A group of more values than a block: select, then the data part as the
+	// metadata says, both over the whole sequence on the device.
+	void encode_long(const std::vector<T> &in, bool aligned)
+	{
+		oroch_sequence_desc rec;
+		hip::check(oroch_sequence_select_host(hip::dtype_of<T>(), in.data(), in.size(), &rec),
+			   "integer_group::encode");
+		byte_t head[40];
+		const int metabytes = oroch_sequence_meta_encode(hip::dtype_of<T>(), &rec, head, sizeof head);
+		hip::check(metabytes < 0 ? metabytes : 0, "integer_group::encode");
+		const size_t offset = aligned ? detail::align8(size_t(metabytes)) : size_t(metabytes);
+		std::vector<byte_t> body(size_t(rec.dataspace) + 16);
+		uint64_t bytes = 0;
+		hip::check(oroch_sequence_encode_host(hip::dtype_of<T>(), in.data(), in.size(), &rec, body.data(),
+						      size_t(rec.dataspace), &bytes),
+			   "integer_group::encode");
+		size_ = offset + size_t(bytes);
+		data_.reset(new byte_t[size_]());
+		std::memcpy(data_.get(), head, size_t(metabytes));
+		std::memcpy(data_.get() + offset, body.data(), size_t(bytes));
+	}
+
 	std::unique_ptr<byte_t[]> data_;
 	size_t size_ = 0;
 };

@@ -7,6 +7,7 @@
 // into one.  The histogram bins the bit length of (v - min()), so every block
 // handed to the device for it carries min() as one extra value: the block
 // minimum then equals min() and the extra value is taken out of bin 0 again.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_INTEGER_STATS_H_
 #define OROCH_INTEGER_STATS_H_
 

@@ -1,6 +1,7 @@
 // integer_traits.h -- signed/unsigned mapping and bit length.
 // Stands in for /root/reference/oroch/integer_traits.h:135-170; usedcount()
 // is the bit length (0 for 0) that bins the histogram and sizes varints.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_INTEGER_TRAITS_H_
 #define OROCH_INTEGER_TRAITS_H_
 

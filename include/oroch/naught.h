@@ -1,6 +1,7 @@
 // naught.h -- the encoding of a constant run: no data bytes at all.
 // Stands in for /root/reference/oroch/naught.h:32-58.  Inside a block image
 // the device encoder and decoder handle it; the standalone form moves no data.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_NAUGHT_H_
 #define OROCH_NAUGHT_H_
 

@@ -1,6 +1,7 @@
 // normal.h -- values stored as they are in memory (little endian).
 // Stands in for /root/reference/oroch/normal.h:32-64.  The standalone form is
 // a byte copy; inside a block image the device kernels do it.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_NORMAL_H_
 #define OROCH_NORMAL_H_
 

@@ -2,6 +2,7 @@
 // Stands in for /root/reference/oroch/offset.h:44-71.  The block path uses
 // only offset_codec<size_t, 1, false> (exception positions); on the device
 // that is an adjacent difference (encode) and a prefix sum (decode).
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_OFFSET_H_
 #define OROCH_OFFSET_H_
 

@@ -1,5 +1,6 @@
 // origin.h -- frame-of-reference value codec: u = unsigned(v - origin).
 // Stands in for /root/reference/oroch/origin.h:36-58 (wrapping arithmetic).
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_ORIGIN_H_
 #define OROCH_ORIGIN_H_
 

@@ -5,6 +5,7 @@
 // run inside the HIP kernels.  What this header keeps on the host is the
 // scalar form (a handful of bytes of metadata) and, for interface parity, the
 // sequence form written as a loop over it.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_VARINT_H_
 #define OROCH_VARINT_H_
 

@@ -3,6 +3,7 @@
 // On the device the same map is fused into the pack / unpack kernels; this
 // class is the value-codec tag the templates are parameterised with, plus the
 // scalar form used for metadata.
+// Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_ZIGZAG_H_
 #define OROCH_ZIGZAG_H_
 

@@ -273,6 +273,14 @@ int oroch_pack_host(int dtype, int vcodec, const void *src_host, size_t n, uint6
 		    unsigned nbits, void *dst_host);
 int oroch_unpack_host(int dtype, int vcodec, const void *src_host, size_t n, uint64_t origin,
 		      unsigned nbits, void *dst_host);
+/*
+ * oroch_bitpck_fetch with HOST pointers (bitpck.h:203-225, 258-266; bitfor.h
+ * :71-74): dst_host[j] = value number index_host[j] of the packed sequence at
+ * src_host.  Only the 16-byte words that hold the wanted values are sent to
+ * the device; the caller vouches that every position lies inside the sequence.
+ */
+int oroch_bitpck_fetch_host(int dtype, int vcodec, const void *src_host, uint64_t origin,
+			    unsigned nbits, const uint64_t *index_host, size_t m, void *dst_host);
 int oroch_bitpfr_encode_host(int dtype, const void *src_host, size_t n, uint64_t origin,
 			     unsigned nbits, void *dst_host, uint64_t *indices_host,
 			     uint64_t *values_host, uint64_t *nexc_host);
@@ -282,6 +290,80 @@ int oroch_bitpfr_decode_host(int dtype, const void *src_host, size_t n, uint64_t
 int oroch_bitpfr_patch_host(int dtype, void *dst_host, size_t n, uint64_t origin, unsigned nbits,
 			    const uint64_t *indices_host, const uint64_t *values_host,
 			    size_t nexc);
+
+/* ---- one group of any length ---------------------------------------------------- */
+
+/*
+ * Codec selection for ONE sequence of any length, the way the reference's
+ * integer_codec<T>::select treats the range it is given (integer_codec.h
+ * :234-384): statistics over the whole sequence, pck(n, b) for the packed part,
+ * one walk over all gaps per candidate width.  The fields are those of
+ * encoding_metadata<T> (integer_codec.h:95-126) at full width.
+ */
+typedef struct oroch_sequence_desc {
+	uint64_t origin;         /* value_desc.origin, raw bits */
+	uint64_t dataspace;      /* value_desc.dataspace */
+	uint64_t noutliers;
+	uint64_t nvalues;
+	uint32_t metaspace;      /* metaspace() = 1 + value_desc.metaspace */
+	uint8_t encoding;        /* value_desc.encoding */
+	uint8_t nbits;           /* value_desc.nbits */
+	uint8_t index_encoding;  /* outlier_index_desc.encoding (bitpfr only) */
+	uint8_t index_nbits;
+	uint8_t value_encoding;  /* outlier_value_desc.encoding (bitpfr only) */
+	uint8_t value_nbits;
+	uint8_t reserved[6];
+} oroch_sequence_desc;
+
+/*
+ * integer_codec<T>::select, integer_codec.h:234-384, on src[0..n) (device) as
+ * one sequence; *desc_host receives the result on a fresh metadata object.
+ * Waits for the stream; allocates its working memory itself.
+ */
+int oroch_sequence_select(int dtype, const void *src, size_t n, oroch_sequence_desc *desc_host,
+			  void *stream);
+/*
+ * integer_codec<T>::encode, integer_codec.h:386-393 (encode_basic :498-528,
+ * bitpfr :562-581): the data part of src[0..n) coded the way *desc_host says,
+ * whoever made the descriptor -- encoding, origin, nbits and, for bitpfr, the
+ * encodings and widths of the two outlier lists are taken from it as they are
+ * (values that do not fit a width the caller chose lose their high bits, as in
+ * the reference).  For bitpfr desc_host->noutliers has to be the number of
+ * values that do not fit nbits (OROCH_E_ARGUMENT otherwise).  dst: device
+ * memory, 16-byte aligned, dst_capacity bytes (OROCH_E_CAPACITY when the data
+ * does not fit; desc_host->dataspace bytes are enough for a descriptor that
+ * select made).  *bytes_host receives the length.  Waits for the stream.
+ */
+int oroch_sequence_encode(int dtype, const void *src, size_t n, const oroch_sequence_desc *desc_host,
+			  void *dst, size_t dst_capacity, uint64_t *bytes_host, void *stream);
+/*
+ * integer_codec<T>::decode, integer_codec.h:395-402 (decode_basic :530-560,
+ * bitpfr :583-609): n values from the data part at src (device, 16-byte
+ * aligned, src_bytes readable bytes) into dst (device).  *consumed_host (may be
+ * NULL) receives the bytes the data part occupies.  Waits for the stream.
+ */
+int oroch_sequence_decode(int dtype, const void *src, size_t src_bytes, size_t n,
+			  const oroch_sequence_desc *desc_host, void *dst, uint64_t *consumed_host,
+			  void *stream);
+/* The three with HOST pointers for values and data. */
+int oroch_sequence_select_host(int dtype, const void *src_host, size_t n, oroch_sequence_desc *desc_host);
+int oroch_sequence_encode_host(int dtype, const void *src_host, size_t n,
+			       const oroch_sequence_desc *desc_host, void *dst_host, size_t dst_capacity,
+			       uint64_t *bytes_host);
+int oroch_sequence_decode_host(int dtype, const void *src_host, size_t src_bytes, size_t n,
+			       const oroch_sequence_desc *desc_host, void *dst_host, uint64_t *consumed_host);
+/*
+ * encoding_metadata<T>::encode / decode, integer_codec.h:128-214 (host
+ * arithmetic): the metadata bytes of a descriptor (at most 32) and back.
+ * Return the number of bytes written / read, or a negative error
+ * (OROCH_E_CAPACITY when fewer than the metadata needs are available).
+ */
+int oroch_sequence_meta_encode(int dtype, const oroch_sequence_desc *desc_host, void *dst_host,
+			       size_t dst_capacity);
+int oroch_sequence_meta_decode(int dtype, const void *src_host, size_t src_bytes,
+			       oroch_sequence_desc *desc_host);
+/* Bytes that always hold the data part of n values whatever select chooses. */
+size_t oroch_sequence_bound(int dtype, size_t n);
 
 /* ---- serialised container ------------------------------------------------------ */
 

@@ -46,4 +46,12 @@ from .capi import (  # noqa: F401
     library_path,
     profile_start,
     profile_stop,
+    sequence_decode,
+    sequence_encode,
+    sequence_group_image,
+    sequence_meta_decode,
+    sequence_meta_encode,
+    sequence_select,
 )
+from . import capi  # noqa: F401,E402
+

@@ -83,6 +83,7 @@ def _load():
         "oroch_group_stats_host": (i, [i, vp, sz, vp]),
         "oroch_pack_host": (i, [i, i, vp, sz, u64, u32, vp]),
         "oroch_unpack_host": (i, [i, i, vp, sz, u64, u32, vp]),
+        "oroch_bitpck_fetch_host": (i, [i, i, vp, u64, u32, vp, sz, vp]),
         "oroch_bitpfr_encode_host": (i, [i, vp, sz, u64, u32, vp, vp, vp, vp]),
         "oroch_bitpfr_decode_host": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp]),
         "oroch_bitpfr_patch_host": (i, [i, vp, sz, u64, u32, vp, vp, sz]),
@@ -109,6 +110,15 @@ def _load():
         "oroch_array_save": (i, [vp, vp, sz, vp]),
         "oroch_array_load": (i, [vp, vp, sz]),
         "oroch_array_view": (i, [vp, vp, vp, vp, vp, vp, vp]),
+        "oroch_sequence_bound": (sz, [i, sz]),
+        "oroch_sequence_select": (i, [i, vp, sz, vp, vp]),
+        "oroch_sequence_encode": (i, [i, vp, sz, vp, vp, sz, vp, vp]),
+        "oroch_sequence_decode": (i, [i, vp, sz, sz, vp, vp, vp, vp]),
+        "oroch_sequence_select_host": (i, [i, vp, sz, vp]),
+        "oroch_sequence_encode_host": (i, [i, vp, sz, vp, vp, sz, vp]),
+        "oroch_sequence_decode_host": (i, [i, vp, sz, sz, vp, vp, vp]),
+        "oroch_sequence_meta_encode": (i, [i, vp, vp, sz]),
+        "oroch_sequence_meta_decode": (i, [i, vp, sz, vp]),
         "oroch_hip_profile_start": (i, [i]),
         "oroch_hip_profile_stop": (i, [vp, vp]),
         "oroch_hip_set_option": (i, [i, i]),
@@ -280,6 +290,76 @@ def varint_decode(b, n, dtype):
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=b.device)
     _check(lib.oroch_varint_decode(code, b.data_ptr(), b.numel(), n, out.data_ptr(), ws.data_ptr(), wsb,
                                    _stream()))
+    return out
+
+
+# ---- one group of any length ------------------------------------------------------------
+
+SEQUENCE_DESC = np.dtype([("origin", "<u8"), ("dataspace", "<u8"), ("noutliers", "<u8"), ("nvalues", "<u8"),
+                          ("metaspace", "<u4"), ("encoding", "u1"), ("nbits", "u1"),
+                          ("index_encoding", "u1"), ("index_nbits", "u1"), ("value_encoding", "u1"),
+                          ("value_nbits", "u1"), ("reserved", "u1", (6,))])
+assert SEQUENCE_DESC.itemsize == 48
+
+
+def sequence_select(x):
+    """integer_codec<T>::select on a 1-D CUDA tensor of any length -> descriptor (numpy record)."""
+    d = np.zeros(1, SEQUENCE_DESC)
+    _check(lib.oroch_sequence_select(dtype_code(x.dtype), x.data_ptr(), x.numel(), d.ctypes.data, _stream()))
+    return d
+
+
+def sequence_encode(x, desc, capacity=None):
+    """The data part of x coded as desc says (uint8 CUDA tensor)."""
+    code = dtype_code(x.dtype)
+    cap = int(desc["dataspace"][0]) if capacity is None else capacity
+    out = _empty_bytes(cap, x.device)
+    total = C.c_uint64(0)
+    _check(lib.oroch_sequence_encode(code, x.data_ptr(), x.numel(), desc.ctypes.data, out.data_ptr(), cap,
+                                     C.byref(total), _stream()))
+    return out[:total.value]
+
+
+def sequence_decode(b, n, desc, dtype):
+    """n values from a data part; returns (values, bytes consumed)."""
+    import torch
+
+    code = dtype_code(dtype)
+    out = torch.empty(n, dtype=_torch_dtype(code), device=b.device)
+    used = C.c_uint64(0)
+    _check(lib.oroch_sequence_decode(code, b.data_ptr(), b.numel(), n, desc.ctypes.data, out.data_ptr(),
+                                     C.byref(used), _stream()))
+    return out, used.value
+
+
+def sequence_meta_encode(desc, dtype):
+    out = np.zeros(40, np.uint8)
+    rc = lib.oroch_sequence_meta_encode(dtype_code(dtype), desc.ctypes.data, out.ctypes.data, out.size)
+    if rc < 0:
+        _check(rc)
+    return out[:rc].copy()
+
+
+def sequence_meta_decode(b, dtype):
+    """Descriptor and number of metadata bytes at the start of a group image (numpy uint8)."""
+    b = np.ascontiguousarray(b, np.uint8)
+    d = np.zeros(1, SEQUENCE_DESC)
+    rc = lib.oroch_sequence_meta_decode(dtype_code(dtype), b.ctypes.data, b.size, d.ctypes.data)
+    if rc < 0:
+        _check(rc)
+    return d, rc
+
+
+def sequence_group_image(x):
+    """integer_group<T>::encode (integer_group.h:44-60, aligned) of a sequence of any
+    length: [metadata][zero pad to 8][data], as numpy bytes."""
+    d = sequence_select(x)
+    meta = sequence_meta_encode(d, x.dtype)
+    data = sequence_encode(x, d).cpu().numpy()
+    at = (meta.size + 7) & ~7
+    out = np.zeros(at + data.size, np.uint8)
+    out[:meta.size] = meta
+    out[at:] = data
     return out
 
 

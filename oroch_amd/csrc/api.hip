@@ -497,6 +497,43 @@ extern "C" int oroch_unpack_host(int dtype, int vcodec, const void *src_host, si
 	return staged_copy(dst_host, out.p, bytes, false, nullptr);
 }
 
+// Only the 16-byte words that hold the wanted values travel: word number j of
+// the upload is the word of query j, and the query is rebased onto it.
+extern "C" int oroch_bitpck_fetch_host(int dtype, int vcodec, const void *src_host, uint64_t origin,
+				       unsigned nbits, const uint64_t *index_host, size_t m, void *dst_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	const size_t cap = oroch_bitpck_capacity(nbits);
+	if (cap == 0 || nbits > (8u << (dtype >> 1)))
+		return OROCH_E_NBITS;
+	if (m == 0)
+		return 0;
+	if (!src_host || !index_host || !dst_host)
+		return OROCH_E_ARGUMENT;
+	try {
+		std::vector<uint8_t> words(m * 16);
+		std::vector<uint64_t> where(m);
+		const uint8_t *src = static_cast<const uint8_t *>(src_host);
+		for (size_t j = 0; j < m; j++) {
+			memcpy(words.data() + j * 16, src + (index_host[j] / cap) * 16, 16);
+			where[j] = j * cap + index_host[j] % cap;
+		}
+		const size_t out_bytes = m << (dtype >> 1);
+		dev_buf in, idx, out;
+		int rc;
+		if ((rc = in.alloc(m * 16)) || (rc = idx.alloc(m * 8)) || (rc = out.alloc(out_bytes)) ||
+		    (rc = staged_copy(in.p, words.data(), m * 16, true, nullptr)) ||
+		    (rc = staged_copy(idx.p, where.data(), m * 8, true, nullptr)) ||
+		    (rc = oroch_bitpck_fetch(dtype, vcodec, in.p, m * cap, origin, nbits,
+					     static_cast<const uint64_t *>(idx.p), m, out.p, nullptr)))
+			return rc;
+		return staged_copy(dst_host, out.p, out_bytes, false, nullptr);
+	} catch (const std::bad_alloc &) {
+		return int(hipErrorOutOfMemory);
+	}
+}
+
 extern "C" int oroch_bitpfr_encode_host(int dtype, const void *src_host, size_t n, uint64_t origin,
 					unsigned nbits, void *dst_host, uint64_t *indices_host,
 					uint64_t *values_host, uint64_t *nexc_host)

@@ -127,6 +127,11 @@ int group_find_within(int dtype, const void *src, const uint64_t *offsets, size_
 int group_at_within(int dtype, const void *src, const uint64_t *offsets, size_t n, const uint64_t *index,
 		    size_t m, void *dst, uint64_t stream_bytes, void *stream);
 
+// oroch_varint_decode that also stores the bytes the n values occupy to
+// *consumed (device memory, may be null); varint.hip.
+int varint_decode_counted(int dtype, const void *src, size_t nbytes, size_t n, void *dst, void *workspace,
+			  size_t workspace_bytes, uint64_t *consumed, void *stream);
+
 // Host-side check of a table of block offsets read from outside: rising,
 // multiples of 16, none beyond stream_bytes.
 bool offsets_table_sound(const uint64_t *table, size_t entries, uint64_t stream_bytes);

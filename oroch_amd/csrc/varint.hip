@@ -176,7 +176,8 @@ __global__ __launch_bounds__(VI_THREADS) void k_varint_count(const uint8_t *src,
 // varint.h:141-147.
 template <typename E>
 __global__ __launch_bounds__(VI_THREADS) void k_varint_take(const uint8_t *src, size_t nbytes, size_t n,
-							      const uint64_t *tile_rank, typename E::S *dst)
+							      const uint64_t *tile_rank, typename E::S *dst,
+							      uint64_t *consumed)
 {
 	using C = typename E::C;
 	__shared__ uint32_t lds[VI_THREADS / WAVE];
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(VI_THREADS) void k_varint_take(const uint8_t *src, 
 	}
 	uint32_t total;
 	uint32_t r = wg_scan_excl(uint32_t(__popc(flags)), lds, &total);
+	const uint64_t rank0 = tile_rank[blockIdx.x];
 	// (wg_scan_excl has synchronised the workgroup: buf is complete)
 	// The tile's values are put together in LDS, in order, and leave in
 	// consecutive stores.
@@ -209,10 +211,12 @@ __global__ __launch_bounds__(VI_THREADS) void k_varint_take(const uint8_t *src, 
 				break;
 			acc = (acc << 7) | (b & 0x7fu);
 		}
+		// where value number n - 1 ends is how many bytes the n values take
+		if (consumed && rank0 + r + 1 == uint64_t(n))
+			*consumed = uint64_t(tile_at) + (p - VI_HALO) + 1u;
 		out[r++] = unzz<E>(C(acc) & E::MASK);
 	}
 	__syncthreads();
-	const uint64_t rank0 = tile_rank[blockIdx.x];
 	for (uint32_t i = threadIdx.x; i < total; i += VI_THREADS) {
 		if (rank0 + i < n)
 			dst[rank0 + i] = typename E::S(out[i]);
@@ -340,8 +344,11 @@ extern "C" int oroch_varint_encode(int dtype, const void *src, size_t n, void *d
 	return rc;
 }
 
-extern "C" int oroch_varint_decode(int dtype, const void *src, size_t nbytes, size_t n, void *dst,
-				   void *workspace, size_t workspace_bytes, void *stream)
+// oroch_varint_decode that also reports, in *consumed (device, may be null;
+// left alone when the bytes hold fewer than n values), the bytes the n values
+// occupy.
+int oroch_hip::varint_decode_counted(int dtype, const void *src, size_t nbytes, size_t n, void *dst,
+				     void *workspace, size_t workspace_bytes, uint64_t *consumed, void *stream)
 {
 	int rc = varint_check(dtype, nbytes, src, workspace, workspace_bytes, nbytes);
 	if (rc)
@@ -363,7 +370,13 @@ extern "C" int oroch_varint_decode(int dtype, const void *src, size_t nbytes, si
 			return r;
 		hipLaunchKernelGGL(k_varint_take<E>, dim3(unsigned(ntiles)), dim3(VI_THREADS), 0, st,
 				   static_cast<const uint8_t *>(src), nbytes, n, w.offs,
-				   static_cast<typename E::S *>(dst));
+				   static_cast<typename E::S *>(dst), consumed);
 		return int(hipGetLastError());
 	});
+}
+
+extern "C" int oroch_varint_decode(int dtype, const void *src, size_t nbytes, size_t n, void *dst,
+				   void *workspace, size_t workspace_bytes, void *stream)
+{
+	return varint_decode_counted(dtype, src, nbytes, n, dst, workspace, workspace_bytes, nullptr, stream);
 }

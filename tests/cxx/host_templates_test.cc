@@ -71,7 +71,8 @@ static void test_stats_select_group()
 {
 	const int dt = oroch::hip::dtype_of<T>();
 	constexpr int W = sizeof(T) * 8;
-	const size_t sizes[] = {1, 2, 4, 5, 8, 31, 100, 255, 256};
+	// up to a block: the block kernels; beyond: one group over the whole-sequence kernels
+	const size_t sizes[] = {1, 2, 4, 5, 8, 31, 100, 255, 256, 257, 1000, 4096};
 	for (int shape = 0; shape < 8; shape++) {
 		for (size_t n : sizes) {
 			const std::vector<T> v = make_block<T>(shape, n);
@@ -557,34 +558,101 @@ static void test_array()
 	REQUIRE(array.empty() && array.find(T(1)) == oroch::not_found);
 }
 
+// tests/bench/group-bench.cc:8-30: one group of 1000 values (0..999), which the
+// selection codes as bitfor or bitpck, encoded and decoded over and over.
+static void test_group_bench_scenario()
+{
+	std::vector<uint32_t> integers(1000), integers2(1000);
+	for (size_t i = 0; i < integers.size(); i++)
+		integers[i] = uint32_t(i);
+	std::vector<uint8_t> want(orc_group_bound(oroch::hip::dtype_of<uint32_t>(), integers.size()) + 64);
+	const size_t wg = orc_group_encode(oroch::hip::dtype_of<uint32_t>(), integers.data(), integers.size(), want.data());
+	oroch::integer_group<uint32_t> group;
+	for (int round = 0; round < 5; round++) {
+		group.encode(integers.begin(), integers.end());
+		REQUIRE(group.size() == wg);
+		REQUIRE(std::memcmp(group.data(), want.data(), wg) == 0);
+		std::fill(integers2.begin(), integers2.end(), 0u);
+		group.decode(integers2.begin(), integers2.end());
+		REQUIRE(integers2 == integers);
+	}
+	oroch::integer_codec<uint32_t>::metadata meta;
+	group.decode(meta);
+	REQUIRE(meta.value_desc.encoding == oroch::bitfor || meta.value_desc.encoding == oroch::bitpck);
+	REQUIRE(meta.value_desc.nbits == 10);
+}
+
+// integer_codec.h:386-393: encode codes the values the way the metadata it is
+// handed says, whether or not select() would have chosen that.
+template <typename T>
+static void test_forced_metadata(size_t n)
+{
+	const int dt = oroch::hip::dtype_of<T>();
+	constexpr int W = sizeof(T) * 8;
+	const std::vector<T> v = make_block<T>(4, n);
+	uint64_t mn, mx, hist[65];
+	orc_stats(dt, v.data(), n, &mn, &mx, hist);
+	unsigned range_bits = 0;
+	for (int b = 0; b <= W; b++)
+		if (hist[b])
+			range_bits = unsigned(b);
+	struct forced { uint32_t encoding, nbits; bool origin; };
+	const forced cases[] = {{oroch::normal, 0, false}, {oroch::varint, 0, false}, {oroch::varfor, 0, true},
+				{oroch::bitpck, uint32_t(W), false}, {oroch::bitfor, range_bits, true}};
+	for (const forced &f : cases) {
+		orc_meta om;
+		std::memset(&om, 0, sizeof om);
+		om.encoding = f.encoding;
+		om.nbits = f.nbits;
+		om.origin = f.origin ? mn : 0;
+		typename oroch::integer_codec<T>::metadata meta;
+		meta.value_desc.encoding = oroch::encoding_t(f.encoding);
+		meta.value_desc.nbits = f.nbits;
+		meta.value_desc.origin = f.origin ? T(typename std::make_unsigned<T>::type(mn)) : T(0);
+		std::vector<uint8_t> want(n * 16 + 64), got(want.size());
+		const size_t wd = orc_codec_encode(dt, v.data(), n, &om, want.data());
+		oroch::dst_bytes_t dp = got.data();
+		oroch::integer_codec<T>::encode(dp, v.begin(), v.end(), meta);
+		REQUIRE(size_t(dp - got.data()) == wd);
+		REQUIRE(std::memcmp(got.data(), want.data(), wd) == 0);
+		std::vector<T> back(n);
+		oroch::src_bytes_t sp = got.data();
+		oroch::integer_codec<T>::decode(back.begin(), back.end(), sp, meta);
+		REQUIRE(size_t(sp - got.data()) == wd);
+		REQUIRE(back == v);
+	}
+}
+
 static void test_errors()
 {
+	// More values than a block in one call: one group, as in the reference.
 	std::vector<int32_t> v(257, 3);
 	oroch::integer_codec<int32_t>::metadata meta;
-	bool thrown = false;
-	try {
-		oroch::integer_codec<int32_t>::select(meta, v.begin(), v.end());
-	} catch (const std::length_error &) {
-		thrown = true;
-	}
-	REQUIRE(thrown);
-	// Metadata that select() would not produce for the values is refused.
-	std::vector<int32_t> w = {1, 2, 3, 4, 5, 6, 7, 8};
-	oroch::integer_codec<int32_t>::select(meta, w.begin(), w.end());
-	meta.value_desc.encoding = oroch::normal;
-	uint8_t buf[256];
-	oroch::dst_bytes_t d = buf;
-	thrown = false;
-	try {
-		oroch::integer_codec<int32_t>::encode(d, w.begin(), w.end(), meta);
-	} catch (const std::logic_error &) {
-		thrown = true;
-	}
-	REQUIRE(thrown);
+	oroch::integer_codec<int32_t>::select(meta, v.begin(), v.end());
+	REQUIRE(meta.value_desc.encoding == oroch::naught && meta.value_desc.origin == 3);
 	// Empty input.
+	std::vector<int32_t> w = {1, 2, 3, 4, 5, 6, 7, 8};
 	oroch::integer_codec<int32_t>::select(meta, w.begin(), w.begin());
 	REQUIRE(meta.value_desc.encoding == oroch::normal);
 	REQUIRE(meta.dataspace() == 0 && meta.metaspace() == 1);
+	// One value out of the middle of a packed sequence (bitpck.h:258-266).
+	std::vector<uint32_t> p(1000);
+	for (size_t i = 0; i < p.size(); i++)
+		p[i] = uint32_t(rnd() & 0x1fff);
+	std::vector<uint8_t> packed(oroch::bitpck_codec<uint32_t>::space(p.size(), 13));
+	oroch::dst_bytes_t d = packed.data();
+	oroch::bitpck_codec<uint32_t>::encode(d, p.begin(), p.end(), 13);
+	for (size_t i : {size_t(0), size_t(8), size_t(9), size_t(500), size_t(999)})
+		REQUIRE(oroch::bitpck_codec<uint32_t>::fetch(packed.data(), i, 13) == p[i]);
+	oroch::bitfor_codec<int32_t>::parameters params(-700, 11);
+	std::vector<int32_t> q(300);
+	for (size_t i = 0; i < q.size(); i++)
+		q[i] = int32_t(rnd() & 0x7ff) - 700;
+	std::vector<uint8_t> framed(oroch::bitfor_codec<int32_t>::space(q.size(), 11));
+	d = framed.data();
+	oroch::bitfor_codec<int32_t>::encode(d, q.begin(), q.end(), params);
+	for (size_t i : {size_t(0), size_t(11), size_t(150), size_t(299)})
+		REQUIRE(oroch::bitfor_codec<int32_t>::fetch(framed.data(), i, params) == q[i]);
 }
 
 template <typename T>
@@ -609,6 +677,11 @@ int main()
 	test_bitpfr_two_calls();
 	test_group_reference_case();
 	test_errors();
+	test_group_bench_scenario();
+	test_forced_metadata<int16_t>(100);
+	test_forced_metadata<int32_t>(256);
+	test_forced_metadata<uint32_t>(3000);
+	test_forced_metadata<int64_t>(700);
 	test_array_reference_cases();
 	run_type<int8_t>("int8");
 	run_type<uint8_t>("uint8");
