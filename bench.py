@@ -61,14 +61,18 @@ def gen_outlier_mix_torch(n, seed, device, body_bits=10, out_bits=28, permille=1
     return out
 
 
-def cpu_baseline(log2n, seed):
+def cpu_baseline(log2n, seed, config="headline"):
     """The reference's own code (oracle/_ref) -- or the C port -- on host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import datagen as dg
     from oracle import pyoracle as po
 
     n = 1 << log2n
-    a = dg.outlier_mix(n, np.int32, seed=seed, shift=-200)
+    if config == "int64mix":
+        a = dg.block_mix_int64(n, seed + 1)
+    else:
+        a = dg.outlier_mix(n, np.int32, seed=seed, shift=-200)
+    name = str(a.dtype)
     nbytes = a.nbytes
     share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, share)
@@ -89,20 +93,20 @@ def cpu_baseline(log2n, seed):
             "value_1thread": gbs(one),
             "phases_1thread_GBps": {"select": nbytes / one[0] / 1e9, "encode": nbytes / one[1] / 1e9,
                                     "decode": nbytes / one[2] / 1e9},
-            "sample": "2^%d int32 values of the bench distribution, blocks of 256, select+encode+"
+            "sample": "2^%d %s values of the bench distribution, blocks of 256, select+encode+"
                       "decode by the reference headers (g++ -O2), best of 2, %d std::threads "
-                      "over disjoint block ranges" % (log2n, threads),
+                      "over disjoint block ranges" % (log2n, name, threads),
         }
     o = po.oracle
     t0 = time.perf_counter()
     stream, offs = o.blocks_encode(a, 256, 16)
     t1 = time.perf_counter()
-    back = o.blocks_decode(stream, offs, n, np.int32, 256)
+    back = o.blocks_decode(stream, offs, n, a.dtype, 256)
     t2 = time.perf_counter()
     assert np.array_equal(back, a)
     return {"value": 2 * nbytes / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "2^%d int32 values of the bench distribution through the C restatement "
-                      "(encode %.2fs, decode %.2fs)" % (log2n, t1 - t0, t2 - t1)}
+            "sample": "2^%d %s values of the bench distribution through the C restatement "
+                      "(encode %.2fs, decode %.2fs)" % (log2n, name, t1 - t0, t2 - t1)}
 
 
 def measured_traffic(direction, log2n):
@@ -122,13 +126,12 @@ def measured_traffic(direction, log2n):
     return (decode if direction == "decode" else encode), rec.get("commit")
 
 
-def end_to_end(x_dev, log2n):
+def end_to_end(x_dev, n):
     """Host buffer -> pinned staging -> device encode -> host stream, and back."""
     import ctypes as C
 
     import oroch_amd
 
-    n = 1 << log2n
     a = x_dev[:n].cpu().numpy()
     code = oroch_amd.dtype_code(a.dtype)
     lib = oroch_amd.lib
@@ -174,7 +177,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2n", type=int, default=30, help="log2 of values per GPU")
+    ap.add_argument("--log2n", type=int, default=30,
+                    help="log2 of values per GPU (weak scaling) or of the whole array (strong scaling)")
+    ap.add_argument("--config", choices=("headline", "int64mix"), default="headline",
+                    help="headline: int32, 10-bit body + 1%% 28-bit outliers; int64mix: int64, eight block "
+                         "shapes in turn (constant, packed, patched, varint, far origin, raw, ramp, 3-bit)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 2^log2n values per GPU; strong: one array of 2^log2n values cut into "
+                         "contiguous block ranges, one per GPU")
     ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -215,13 +225,27 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    n = 1 << args.log2n
     seed = 3
-    # rank r owns values [r*n, (r+1)*n) of the N*n-value array
-    x = gen_outlier_mix_torch(n, seed, device, start=rank * n)
-    enc = oroch_amd.GroupEncoder(np.int32, n, device)
+    if args.scaling == "strong":
+        # one array, rank r owns the block range shard_range gives it
+        start, stop = sharding.shard_range(1 << args.log2n, rank, world)
+        n = stop - start
+    else:
+        # rank r owns values [r*n, (r+1)*n) of the N*n-value array
+        n = 1 << args.log2n
+        start = rank * n
+    if args.config == "int64mix":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import devgen
+
+        np_dtype, width = np.int64, 8
+        x = devgen.block_mix_int64(n, seed + 1, device, start=start)
+    else:
+        np_dtype, width = np.int32, 4
+        x = gen_outlier_mix_torch(n, seed, device, start=start)
+    enc = oroch_amd.GroupEncoder(np_dtype, n, device)
     back = torch.empty_like(x)
-    code = oroch_amd.dtype_code(np.int32)
+    code = oroch_amd.dtype_code(np_dtype)
 
     def encode():
         enc.encode(x)
@@ -267,9 +291,10 @@ def main():
 
     counts = sharding.gather_byte_counts(total, device)
     if rank == 0:
-        raw = n * 4
+        raw = n * width  # rank 0's share; every rank holds as much (the last of a strong split maybe less)
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * 2 * raw / (elapsed / args.steps) / 1e9
+        values_all = (1 << args.log2n) if args.scaling == "strong" else world * n
+        value = 2 * values_all * width / (elapsed / args.steps) / 1e9
         kern = {}
         for name, (ms, cnt) in prof.items():
             kern[name] = ms / cnt
@@ -286,17 +311,24 @@ def main():
         for d, p in paths.items():
             p["achieved"] = p["algorithmic_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] else 0.0
             p["frac"] = p["achieved"] / HBM_PEAK_GBS
-            p["traffic"], p["traffic_commit"] = measured_traffic(d, args.log2n)
+            p["traffic"], p["traffic_commit"] = (measured_traffic(d, args.log2n) if args.config == "headline"
+                                                 and n == 1 << 30 else (None, None))
         # the figure of merit is the slower direction
         worse = min(paths, key=lambda d: paths[d]["frac"])
         line = {
-            "metric": "device-resident encode+decode GB/s (uncompressed bytes), per-block bitpfr int32",
+            "metric": "device-resident encode+decode GB/s (uncompressed bytes), per-block "
+                      + ("bitpfr int32" if args.config == "headline" else "selection int64 mix"),
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "int32 2^%d values per GPU, 10-bit body + 1%% 28-bit outliers, "
-                                   "shift -200, blocks of 256, select+scan+encode then decode"
-                                   % args.log2n,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "int32" if width == 4 else "int64",
+            "data": "synthetic",
+            "config": {"workload": ("int32 2^%d values %s, 10-bit body + 1%% 28-bit outliers, shift -200, "
+                                    if args.config == "headline" else
+                                    "int64 2^%d values %s, eight block shapes in turn (constant, 12-bit, "
+                                    "12-bit + 1%% 40-bit outliers, signed geometric, far origin, raw, ramp, "
+                                    "3-bit), ") % (args.log2n, "per GPU" if args.scaling == "weak"
+                                                  else "in all, cut into one block range per GPU")
+                                   + "blocks of 256, select+scan+encode then decode",
                        "values_per_gpu": n, "block_values": 256,
                        "compressed_bytes_per_gpu": total,
                        "compressed_over_raw": total / raw, "parallelism": "blocks sharded over %d GPU(s), "
@@ -313,9 +345,9 @@ def main():
             "shard_bytes": counts,
         }
         if world == 1 and not args.no_end_to_end:
-            line["end_to_end"] = end_to_end(x, min(args.log2n, 27))
+            line["end_to_end"] = end_to_end(x, min(n, 1 << 27))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed, args.config)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -46,3 +46,53 @@ def max_over_ranks(seconds, device, group=None):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+# ---- one whole-sequence bitpfr code split over ranks ---------------------------------
+#
+# bitpfr over a whole array (bitpfr.h:95-124) is one run of 16-byte words of
+# cap = 128 // nbits values each, plus two lists with one entry per value that
+# does not fit: the gap to the previous such value (offset.h:55-60) and the
+# high bits.  Cut at multiples of cap, the packed words of the shards
+# concatenate to the words of the whole array; the value lists concatenate as
+# they are; of the gap lists only the first entry of each shard changes: it was
+# counted from the shard's first value and has to count from the last
+# exception of the shards before it.  What the ranks exchange is two numbers
+# each: how many exceptions they found and where the last one sits.
+
+
+def whole_array_range(n, rank, world, nbits):
+    """[lo, hi) of rank's range of one packed sequence; boundaries are multiples of
+    the values per 16-byte word, so every shard starts a fresh word."""
+    cap = 128 // nbits
+    nwords = (n + cap - 1) // cap
+    per = (nwords + world - 1) // world
+    lo = min(rank * per, nwords) * cap
+    hi = min((rank + 1) * per, nwords) * cap
+    return min(lo, n), min(hi, n)
+
+
+def gather_exception_summaries(count, last_position, device, group=None):
+    """[(exceptions, global position of the last one or -1)] of all ranks, in rank order."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [(int(count), int(last_position))]
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(count), int(last_position)], dtype=torch.int64, device=device)
+    out = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [(int(t[0].item()), int(t[1].item())) for t in out]
+
+
+def first_gap_fixup(summaries, rank, lo):
+    """What to add to the first gap of rank's list: the distance from the value after
+    the last exception of the earlier shards (value 0 if there is none) to lo."""
+    after = 0
+    for count, last in summaries[:rank]:
+        if count:
+            after = last + 1
+    return lo - after
+
+
+def exception_base(summaries, rank):
+    """Index of rank's first exception in the concatenated lists."""
+    return sum(count for count, _ in summaries[:rank])

@@ -106,3 +106,29 @@ def fuzz_block(rng, dt, n):
                                                    np.uint64(1) << np.uint64(W - 2))
     with np.errstate(over="ignore"):
         return np.ascontiguousarray(v.astype(np.uint64).astype(u).view(dt))
+
+
+def block_mix_int64(n, seed, block=256, start=0):
+    """devgen.block_mix_int64 on the host: eight block shapes chosen by block id
+    mod 8 (constant, 12-bit uniform, 12-bit with 1 % 40-bit outliers, signed with
+    geometric magnitudes, large origin with small deltas, full 64-bit random,
+    ramp, 3-bit)."""
+    U = np.uint64
+    r = h(seed, n, start)
+    i = np.arange(start, start + n, dtype=np.uint64)
+    blk = i // U(block)
+    kind = blk % U(8)
+    with np.errstate(over="ignore"):
+        const = ((blk * U(0x9E3779B97F4A7C15)).view(np.int64) >> 7).view(np.uint64)
+        u12 = r & U(0xfff)
+        sel = ((r >> U(32)) % U(100)) == 0
+        out40 = np.where(sel, u12 | (((r >> U(12)) | U(1 << 39)) & U((1 << 40) - 1)), u12)
+        k = (r & U(63)) % U(36)
+        mag = (r >> U(8)) & ((U(1) << k) - U(1))
+        small = np.where((r & U(64)) != 0, U(0) - mag, mag)
+        far = U(1 << 50) + (r & U(0xfff))
+        ramp = (i % U(block)) * U(3) + blk
+    v = const
+    for kk, cand in ((1, u12), (2, out40), (3, small), (4, far), (5, r), (6, ramp), (7, r & U(7))):
+        v = np.where(kind == U(kk), cand, v)
+    return v.view(np.int64)

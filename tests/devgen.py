@@ -24,11 +24,12 @@ def h(seed, n, start, device):
     return z ^ lsr(z, 31)
 
 
-def chunks(n, fn, dtype, device, chunk=1 << 26):
+def chunks(n, fn, dtype, device, chunk=1 << 26, start=0):
+    """fn(first index, count) for pieces of [start, start + n), written into one tensor."""
     out = torch.empty(n, dtype=dtype, device=device)
     for lo in range(0, n, chunk):
         m = min(chunk, n - lo)
-        out[lo:lo + m] = fn(lo, m).to(dtype)
+        out[lo:lo + m] = fn(start + lo, m).to(dtype)
     return out
 
 
@@ -46,10 +47,11 @@ def outlier_mix(n, dtype, seed, device, body_bits=10, out_bits=28, permille=10, 
     return chunks(n, fn, dtype, device)
 
 
-def block_mix_int64(n, seed, device, block=256):
+def block_mix_int64(n, seed, device, block=256, start=0):
     """Eight block shapes chosen by block id mod 8: constant, 12-bit uniform,
     12-bit with 1 % 40-bit outliers, signed with geometric magnitudes, large origin with
-    small deltas, full 64-bit random, ramp, 3-bit."""
+    small deltas, full 64-bit random, ramp, 3-bit.  Values [start, start + n) of the
+    endless sequence (start a multiple of block)."""
     def fn(lo, m):
         r = h(seed, m, lo, device)
         i = torch.arange(lo, lo + m, dtype=torch.int64, device=device)
@@ -68,4 +70,4 @@ def block_mix_int64(n, seed, device, block=256):
         for k, cand in ((1, u12), (2, out40), (3, small), (4, far), (5, r), (6, ramp), (7, r & 7)):
             v = torch.where(kind == k, cand, v)
         return v
-    return chunks(n, fn, torch.int64, device, chunk=1 << 25)
+    return chunks(n, fn, torch.int64, device, chunk=1 << 25, start=start)

@@ -38,3 +38,26 @@ def test_bench_prints_one_complete_line():
     # the figure of merit is the slower of the two directions
     assert abs(r["frac"] - min(r["encode_path"]["frac"], r["decode_path"]["frac"])) < 1e-9
     assert r["kernel"].split()[0] in ("encode", "decode")
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_of_the_int64_mix():
+    """One int64 array cut into block ranges: alone, and as two ranks that share
+    the one GPU of this box (gloo between them; the ranks exchange byte counts only)."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "int64mix", "--scaling", "strong",
+            "--log2n", "21", "--steps", "2", "--warmup", "1", "--cpu-log2n", "16"]
+    lines = {}
+    for world, extra in ((1, []), (2, ["--gpus", "2", "--one-device", "--backend", "gloo"])):
+        env = dict(os.environ, MASTER_PORT="29533")
+        out = subprocess.run(base + extra, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(got) == 1, out.stdout[-2000:]
+        lines[world] = json.loads(got[0])
+    for world, d in lines.items():
+        assert d["n_gpus"] == world and d["scaling"] == "strong" and d["dtype"] == "int64"
+        assert "int64" in d["metric"] and "int64 2^21 values in all" in d["config"]["workload"]
+        assert len(d["shard_bytes"]) == world and d["value"] > 0
+    # the shards of the two ranks together are the stream of the one
+    assert sum(lines[2]["shard_bytes"]) == lines[1]["shard_bytes"][0]
+    assert lines[2]["config"]["values_per_gpu"] == (1 << 20)
