@@ -13,7 +13,20 @@
 
 namespace oroch_hip {
 
-constexpr int HQ_DWORDS = 196;  // per group: 34 bins x 4 copies; 196 puts the groups' tables 4 banks apart
+// Histogram bins are kept in HQ_COPIES copies each, one per lane number modulo
+// HQ_COPIES, so that fewer lanes of a group add to the same word in one
+// instruction: with the usual narrow spread of bit lengths most of a group's
+// sixteen lanes hit two or three bins, and words that several lanes add to are
+// served one lane after the other.
+#ifndef HQ_COPIES
+#define HQ_COPIES 4
+#endif
+constexpr int HQ_BINS = 35;     // "zero or minus one", zero, and bit lengths 32 down to 1
+// per group: HQ_BINS x HQ_COPIES words, padded so that the four groups' tables sit
+// HQ_COPIES banks apart (16 copies: half the banks)
+constexpr int HQ_DWORDS = HQ_COPIES == 4 ? 196 : HQ_COPIES == 8 ? 296 : 560;
+static_assert(HQ_COPIES == 4 || HQ_COPIES == 8 || HQ_COPIES == 16, "copies per bin");
+static_assert(HQ_DWORDS >= HQ_BINS * HQ_COPIES && HQ_DWORDS % 4 == 0, "room for every bin");
 constexpr int NO_DWORDS = 64;   // per group: exception counts by width, zero above the widest
 constexpr int PW_ENTRIES = 34;  // per group: per-width candidate parameters
 
@@ -141,30 +154,31 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	}
 	const uint32_t vo = vsp(zz<E>(mn));
 
-	// Bit-length histograms of v - min and of zigzag(v), integer_stats.h:97-102.
-	// Bins are indexed by leading zeros + 1 (v_ffbh_u32 gives -1 for zero, so
-	// bin 0 is "value zero" and bin c + 1 is bit length 32 - c) and are four
-	// dwords each (one per sub & 3, to spread same-address atomics): delta
-	// count in the low half, zigzag count in the high half.
-	//
-	// For a signed type the bit length of zigzag(v) is 33 minus the number of
-	// leading bits of v that equal its sign, which one instruction counts;
-	// it answers -1 for both 0 and -1, and those go to a bin of their own in
-	// front of bin 0.  Nothing below tells them apart: both cost one varint
-	// byte, and a block of nothing else packs at width 1 either way.
-	uint32_t *table = hq + mul24(uint32_t(g), HQ_DWORDS) + 4;
+	// Bit-length histogram of v - min, integer_stats.h:97-102.  Bins are indexed
+	// by leading zeros + 1 (v_ffbh_u32 gives -1 for zero, so bin 0 is "value
+	// zero" and bin c + 1 is bit length 32 - c) and are HQ_COPIES words each (one
+	// per sub modulo HQ_COPIES, to spread same-address atomics).
+	constexpr int NC = HQ_COPIES;
+	uint32_t *table = hq + mul24(uint32_t(g), HQ_DWORDS) + NC;
 #pragma unroll
-	for (int k = 0; k < HQ_DWORDS / (GROUP * 4); k++)
-		*reinterpret_cast<uint4 *>(&table[(k * GROUP + sub) * 4 - 4]) = make_uint4(0, 0, 0, 0);
+	for (int k = 0; k < (HQ_BINS * NC + GROUP * 4 - 1) / (GROUP * 4); k++)
+		if ((k * GROUP + sub) * 4 < HQ_DWORDS)
+			*reinterpret_cast<uint4 *>(&table[(k * GROUP + sub) * 4 - NC]) = make_uint4(0, 0, 0, 0);
 	uint32_t *nog = no + g * NO_DWORDS;
 	nog[32 + sub] = 0;
 	nog[48 + sub] = 0;
 	wave_sync();
-	uint32_t *mine = table + 4 + (sub & 3);
-	uint32_t *minez = E::sgn ? mine - 4 : mine;
+	uint32_t *mine = table + NC + (sub & (NC - 1));
 	// leading-zero counts of the deltas, four to a register (value 4j + r in
 	// byte j of lz[r]; 255 for a zero delta)
 	int cds[VPQ];
+	// The zigzag images need no histogram: what selection wants of them is the
+	// sum of their varint lengths and the longest of them.  A value whose
+	// zigzag image is L bits long takes ceil(L / 7) = (37 L + 219) >> 8 bytes
+	// (L in 1..32; zero takes one byte like L = 1), and L is ZL minus the
+	// count of redundant leading bits, clamped for the "none at all" answer.
+	constexpr uint32_t ZL = E::sgn ? 33u : 32u, ZCAP = ZL - 1u;
+	uint32_t zbytes = 0, zlead = ZCAP;
 #pragma unroll
 	for (int i = 0; i < VPQ; i++) {
 		const int cd = leading_zeros(uint32_t((v[i] - mn) & E::MASK));
@@ -173,8 +187,10 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 			cz = leading_sign_bits(int32_t(v[i] << (32 - E::W)) >> (32 - E::W));
 		else
 			cz = leading_zeros(uint32_t(v[i]));
-		atomicAdd(&mine[cd * 4], 1u);
-		atomicAdd(&minez[cz * 4], 0x10000u);
+		atomicAdd(&mine[cd * NC], 1u);
+		const uint32_t czc = uint32_t(cz) < ZCAP ? uint32_t(cz) : ZCAP; // -1 reads as huge
+		zbytes += (37u * ZL + 219u - mul24(czc, 37u)) >> 8;
+		zlead = czc < zlead ? czc : zlead;
 		cds[i] = cd;
 	}
 	uint32_t lz[4];
@@ -187,29 +203,28 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	}
 	wave_sync();
 	// width b <-> bin 33 - b
-	const uint4 qa = *reinterpret_cast<const uint4 *>(&table[(33u - bA) * 4]);
-	const uint4 qb = *reinterpret_cast<const uint4 *>(&table[(33u - bB) * 4]);
-	const uint4 q0 = *reinterpret_cast<const uint4 *>(&table[0]);
-	const uint32_t sa = qa.x + qa.y + qa.z + qa.w;
-	const uint32_t sb = qb.x + qb.y + qb.z + qb.w;
-	uint32_t s0 = q0.x + q0.y + q0.z + q0.w;
-	if constexpr (E::sgn) {
-		// the zigzag half of the zero count sits one bin lower
-		const uint4 qm = *reinterpret_cast<const uint4 *>(&table[-4]);
-		s0 = (s0 & 0xffffu) + ((qm.x + qm.y + qm.z + qm.w) & 0xffff0000u);
-	}
-	const uint32_t dA = sa & 0xffffu, zA = sa >> 16, dB = sb & 0xffffu, zB = sb >> 16;
-	const uint32_t zero_d = s0 & 0xffffu, zero_z = s0 >> 16;
+	auto bin_sum = [&](const uint32_t *at) {
+		uint32_t total = 0;
+#pragma unroll
+		for (int k = 0; k < NC; k += 4) {
+			const uint4 q = *reinterpret_cast<const uint4 *>(at + k);
+			total += q.x + q.y + q.z + q.w;
+		}
+		return total;
+	};
+	const uint32_t sa = bin_sum(&table[(33u - bA) * NC]);
+	const uint32_t sb = bin_sum(&table[(33u - bB) * NC]);
+	uint32_t s0 = bin_sum(&table[0]);
+	const uint32_t dA = sa, dB = sb, zero_d = s0;
 	const bool constant = zero_d == uint32_t(BLOCK); // integer_codec.h:255-264, applied at the end
 
 	// the two varint footprints, integer_codec.h:483-489, from the histograms
 	const uint32_t wA = lc.wA, wB = lc.wB;
-	const uint32_t t = row_sum(mul24(dA, wA) + mul24(dB, wB) + ((mul24(zA, wA) + mul24(zB, wB)) << 16));
-	const uint32_t vfs = (t & 0xffffu) + zero_d, vis = (t >> 16) + zero_z;
-	// widest delta and widest zigzag image
+	const uint32_t t = row_sum(mul24(dA, wA) + mul24(dB, wB) + (zbytes << 16));
+	const uint32_t vfs = (t & 0xffffu) + zero_d, vis = t >> 16;
+	// widest delta and widest zigzag image (at least one bit, bitpck.h:54-57)
 	const uint32_t nbmax = row_max(dB ? bB : (dA ? bA : 0u));
-	uint32_t nbz = row_max(zB ? bB : (zA ? bA : 0u));
-	nbz = nbz ? nbz : 1u;
+	const uint32_t nbz = ZL - row_min(zlead);
 
 	// select_basic, integer_codec.h:422-496; strictly smaller replaces (:413)
 	uint32_t best = BLOCK * E::BYTES, bmeta0 = 0;
@@ -263,7 +278,7 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	const uint32_t basic_meta = 1 + vo;
 	uint4 *pwg = pw + mul24(uint32_t(g), PW_ENTRIES);
 	bool candA, candB;
-	uint32_t estA, estB;
+	uint32_t estA, estB, lowA = 0, lowB = 0; // lowX: what the width needs at the very least
 	{
 		const bool active = bA < nbmax && dA != 0;
 		const uint32_t xmeta = 2 + (noutA < 128u ? 1u : 2u);
@@ -276,6 +291,7 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint32_t est = fixed + indmin;
 		candA = active;
 		estA = est;
+		lowA = fixed + (noutA < indmin ? noutA : indmin); // a varint list of one-byte gaps
 		pwg[bA] = make_uint4(est, fixed, noutA | (venc << 16) | (xmeta << 24), 0);
 	}
 	candB = false;
@@ -292,6 +308,7 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint32_t indmin = noutB > 128u ? 32u : 16u;
 		const uint32_t fixed = basic_meta + xmeta + lc.pckB + vdata;
 		estB = fixed + indmin;
+		lowB = fixed + (noutB < indmin ? noutB : indmin);
 		candB = active;
 		pwg[bB] = make_uint4(estB, fixed, noutB | (venc << 16) | (xmeta << 24), 0);
 	}
@@ -299,25 +316,9 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 	candB = candB && !constant;
 	wave_sync();
 
-	// Replay of the reference's ascending loop, all four blocks in step: each
-	// group takes its narrowest remaining candidate.  `best` only shrinks, so
-	// a width that failed the gate (:327-335) against the initial value fails later.
-	// A width whose estimate is not below `best` fails the gate now and, as
-	// `best` only shrinks, ever after: each round a group moves straight on to
-	// its narrowest remaining width that passes.
-	uint32_t got = 0, gotpar = 0;
-	for (;;) {
-		candA = candA && estA < best;
-		candB = candB && estB < best;
-		const uint64_t ballA = __ballot(candA), ballB = __ballot(candB);
-		if ((ballA | ballB) == 0)
-			break;
-		const uint32_t cands = group_bits(ballA, g) | (group_bits(ballB, g) << 16); // bit b - 1
-		const bool tryit = cands != 0;
-		const uint32_t bL = uint32_t(__builtin_ctz(cands | 0x80000000u)) + 1u;
-		candA = candA && bA != bL;
-		candB = candB && bB != bL;
-		const uint4 par = pwg[tryit ? bL : 1u];
+	// One candidate width of each block, all four blocks in step: the index
+	// list of width bL (integer_codec.h:338-351) and what the block then takes.
+	auto evaluate = [&](uint32_t bL, const uint4 &par, uint32_t &required, uint32_t &how) {
 		const uint32_t fixedL = par.y, noutL = par.z & 0xffffu;
 		// My exceptions at this width, bit i for value i: bit length above bL,
 		// i.e. fewer than 32 - bL leading zeros (a zero delta reads as 255).
@@ -357,11 +358,73 @@ __device__ __forceinline__ void select_quad(const typename E::C (&v)[VPQ], int l
 		const uint32_t indpck = pck_bytes(noutL, ci);
 		const uint32_t ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
 		const uint32_t idata = indpck < indvar ? indpck : indvar;
-		const uint32_t required = fixedL + idata;
-		if (tryit && required < best) {
+		required = fixedL + idata;
+		how = bL | (ienc == OROCH_BITPCK ? indnbits << 8 : 0u) | (ienc << 16);
+	};
+
+	uint32_t got = 0, gotpar = 0;
+	// The reference walks the widths upwards; a width is looked at when its
+	// estimate is below the best total so far (:327-335) and adopted when what
+	// it really needs is below it too (:353-383).  Widths whose estimate is
+	// not below the best of the basic encodings never get looked at.  Of the
+	// others, take the one whose lower bound (the index list at its
+	// shortest) is lowest and evaluate it: if both its estimate and its real
+	// need are below every other width's lower bound (and below the basic
+	// best), the walk adopts exactly this width -- nothing before it can have
+	// pushed the best total low enough to hide it, nothing after it can beat
+	// it -- and one evaluation has replaced the walk.  Otherwise the walk runs.
+	candA = candA && estA < best;
+	candB = candB && estB < best;
+	bool walk;
+	{
+		const uint32_t keyA = candA ? (lowA << 6) | (bA - 1u) : ~0u;
+		const uint32_t keyB = candB ? (lowB << 6) | (bB - 1u) : ~0u;
+		const uint32_t first = row_min(keyA < keyB ? keyA : keyB);
+		const uint32_t restA = keyA == first ? ~0u : keyA, restB = keyB == first ? ~0u : keyB;
+		const uint32_t second = row_min(restA < restB ? restA : restB);
+		const bool any = first != ~0u;
+		const uint32_t bL = any ? (first & 63u) + 1u : 1u;
+		const uint4 par = pwg[bL];
+		uint32_t required, how;
+		evaluate(bL, par, required, how);
+		const uint32_t est = par.x;
+		const uint32_t top = required > est ? required : est;
+		const uint32_t bound = best < (second >> 6) ? best : (second >> 6); // second >> 6 is huge when there is none
+		const bool settled = top < bound;
+		if (any && settled) {
 			best = required;
-			got = bL | (ienc == OROCH_BITPCK ? indnbits << 8 : 0u) | (ienc << 16);
+			got = how;
 			gotpar = par.z;
+		}
+		walk = any && !settled;
+	}
+	if (__ballot(walk) != 0) {
+		// Replay of the reference's ascending loop for the groups that need it
+		// (the others idle through): each group takes its narrowest remaining
+		// candidate.  `best` only shrinks, so a width whose estimate is not
+		// below it fails the gate now and ever after: each round a group moves
+		// straight on to its narrowest remaining width that passes.
+		candA = candA && walk;
+		candB = candB && walk;
+		for (;;) {
+			candA = candA && estA < best;
+			candB = candB && estB < best;
+			const uint64_t ballA = __ballot(candA), ballB = __ballot(candB);
+			if ((ballA | ballB) == 0)
+				break;
+			const uint32_t cands = group_bits(ballA, g) | (group_bits(ballB, g) << 16); // bit b - 1
+			const bool tryit = cands != 0;
+			const uint32_t bL = uint32_t(__builtin_ctz(cands | 0x80000000u)) + 1u;
+			candA = candA && bA != bL;
+			candB = candB && bB != bL;
+			const uint4 par = pwg[tryit ? bL : 1u];
+			uint32_t required, how;
+			evaluate(bL, par, required, how);
+			if (tryit && required < best) {
+				best = required;
+				got = how;
+				gotpar = par.z;
+			}
 		}
 	}
 	if (got) {
