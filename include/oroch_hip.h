@@ -249,9 +249,10 @@ int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size
 /* ---- host-buffer conveniences (stage through pinned memory, synchronous) -- */
 
 /*
- * Same as oroch_group_encode / oroch_group_decode with HOST pointers: copies
- * in over pinned staging buffers, runs the device path, copies the stream and
- * the offsets back.  dst_capacity >= oroch_group_bound(); offsets_host holds
+ * Same as oroch_group_encode / oroch_group_decode with HOST pointers: the
+ * array goes through a pipe (see oroch_pipe_create) that the library makes on
+ * first use per device and keeps, in chunks, with copies in, kernels and
+ * copies out overlapped.  dst_capacity >= oroch_group_bound(); offsets_host holds
  * ceil(n / block) + 1 entries.  Returns the stream length in *total_host.
  */
 int oroch_group_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
@@ -290,6 +291,31 @@ int oroch_bitpfr_decode_host(int dtype, const void *src_host, size_t n, uint64_t
 int oroch_bitpfr_patch_host(int dtype, void *dst_host, size_t n, uint64_t origin, unsigned nbits,
 			    const uint64_t *indices_host, const uint64_t *values_host,
 			    size_t nexc);
+
+/* ---- host buffers through an overlapped pipeline -------------------------------- */
+
+/*
+ * A pipe owns two sets of device buffers, pinned staging buffers and three
+ * streams, all allocated by oroch_pipe_create and kept until
+ * oroch_pipe_destroy; encode and decode through it allocate nothing.  The
+ * array is cut into chunks of chunk_bytes of values (0: 64 MiB; rounded up to
+ * whole blocks): while chunk k is encoded, chunk k + 1 travels to the device
+ * and the stream of chunk k - 1 travels back, so the two directions of the
+ * link and the kernels work at the same time (blocks are independent,
+ * integer_group.h:44-76; a chunk's offsets are rebased by the length of the
+ * stream before it).  Results are those of oroch_group_encode_host /
+ * oroch_group_decode_host.  Caller buffers that are pinned (hipHostMalloc,
+ * hipHostRegister) go over the link as they are, others through the pipe's
+ * staging buffers.  One call at a time per pipe (calls are serialised inside);
+ * a pipe belongs to the device that was current when it was made.
+ */
+typedef struct oroch_pipe oroch_pipe;
+int oroch_pipe_create(size_t chunk_bytes, oroch_pipe **out);
+void oroch_pipe_destroy(oroch_pipe *pipe);
+int oroch_pipe_encode(oroch_pipe *pipe, int dtype, const void *src_host, size_t n, void *dst_host,
+		      size_t dst_capacity, uint64_t *offsets_host, uint64_t *total_host);
+int oroch_pipe_decode(oroch_pipe *pipe, int dtype, const void *src_host, const uint64_t *offsets_host,
+		      size_t n, void *dst_host);
 
 /* ---- one group of any length ---------------------------------------------------- */
 

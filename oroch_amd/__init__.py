@@ -13,6 +13,7 @@ from .capi import (  # noqa: F401
     IntegerArray,
     NOT_FOUND,
     OrochError,
+    Pipe,
     bitfor_decode,
     bitfor_encode,
     bitpck_decode,

@@ -110,6 +110,10 @@ def _load():
         "oroch_array_save": (i, [vp, vp, sz, vp]),
         "oroch_array_load": (i, [vp, vp, sz]),
         "oroch_array_view": (i, [vp, vp, vp, vp, vp, vp, vp]),
+        "oroch_pipe_create": (i, [sz, vp]),
+        "oroch_pipe_destroy": (None, [vp]),
+        "oroch_pipe_encode": (i, [vp, i, vp, sz, vp, sz, vp, vp]),
+        "oroch_pipe_decode": (i, [vp, i, vp, vp, sz, vp]),
         "oroch_sequence_bound": (sz, [i, sz]),
         "oroch_sequence_select": (i, [i, vp, sz, vp, vp]),
         "oroch_sequence_encode": (i, [i, vp, sz, vp, vp, sz, vp, vp]),
@@ -291,6 +295,50 @@ def varint_decode(b, n, dtype):
     _check(lib.oroch_varint_decode(code, b.data_ptr(), b.numel(), n, out.data_ptr(), ws.data_ptr(), wsb,
                                    _stream()))
     return out
+
+
+# ---- host buffers through an overlapped pipeline ------------------------------------------
+
+
+class Pipe:
+    """oroch_pipe_*: encode / decode of host arrays in chunks, copies and kernels overlapped.
+    Buffers may be numpy arrays (pageable) or pinned torch tensors viewed as numpy."""
+
+    def __init__(self, chunk_bytes=0):
+        self._h = C.c_void_p()
+        _check(lib.oroch_pipe_create(chunk_bytes, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.oroch_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def encode(self, a, out=None, offsets=None):
+        """a: 1-D numpy array.  Returns (stream bytes, offsets) as numpy views of out / offsets."""
+        code = dtype_code(a.dtype)
+        n = a.size
+        bound = lib.oroch_group_bound(code, n)
+        if out is None:
+            out = np.empty(bound, np.uint8)
+        if offsets is None:
+            offsets = np.empty((n + BLOCK_VALUES - 1) // BLOCK_VALUES + 1, np.uint64)
+        total = C.c_uint64(0)
+        _check(lib.oroch_pipe_encode(self._h, code, a.ctypes.data, n, out.ctypes.data, out.size,
+                                     offsets.ctypes.data, C.byref(total)))
+        return out[:total.value], offsets
+
+    def decode(self, stream, offsets, n, dtype, out=None):
+        code = dtype_code(dtype)
+        if out is None:
+            out = np.empty(n, DTYPES[code])
+        _check(lib.oroch_pipe_decode(self._h, code, stream.ctypes.data, offsets.ctypes.data, n, out.ctypes.data))
+        return out
 
 
 # ---- one group of any length ------------------------------------------------------------

@@ -204,12 +204,10 @@ extern "C" const char *oroch_hip_strerror(int code)
 	return "unknown error";
 }
 
-namespace {
-
 // memcpy split over a few threads: one core moves 10-12 GB/s between pageable
 // and pinned memory, a fifth of what the link to the device carries.
 // OROCH_HIP_COPY_THREADS overrides the thread count (default 8, at most 32).
-void parallel_memcpy(void *dst, const void *src, size_t bytes)
+void oroch_hip::parallel_memcpy(void *dst, const void *src, size_t bytes)
 {
 	static const unsigned nthreads = [] {
 		const char *v = getenv("OROCH_HIP_COPY_THREADS");
@@ -237,6 +235,10 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes)
 	for (auto &th : team)
 		th.join();
 }
+
+namespace {
+
+using oroch_hip::parallel_memcpy;
 
 // The two pinned staging buffers are kept for the life of the process (pinning
 // 64 MiB costs milliseconds); one staged copy runs at a time.
@@ -347,31 +349,9 @@ extern "C" int oroch_group_encode_host(int dtype, const void *src_host, size_t n
 {
 	if (dtype < 0 || dtype > 7)
 		return OROCH_E_DTYPE;
-	if (!offsets_host || !total_host || (n && (!src_host || !dst_host)))
-		return OROCH_E_ARGUMENT;
-	const size_t bytes = n << (dtype >> 1);
-	const size_t bound = oroch_group_bound(dtype, n);
-	const size_t nblocks = (n + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
-	dev_buf in, out, offs, ws;
-	int rc;
-	if ((rc = in.alloc(bytes)) || (rc = out.alloc(bound)) ||
-	    (rc = offs.alloc((nblocks + 1) * sizeof(uint64_t))) ||
-	    (rc = ws.alloc(oroch_group_workspace(dtype, n))))
-		return rc;
-	hipStream_t st = nullptr;
-	if ((rc = staged_copy(in.p, src_host, bytes, true, st)))
-		return rc;
-	uint64_t total = 0;
-	rc = oroch_group_encode(dtype, in.p, n, out.p, bound, static_cast<uint64_t *>(offs.p), ws.p,
-				oroch_group_workspace(dtype, n), &total, st);
-	if (rc)
-		return rc;
-	*total_host = total;
-	if (total > dst_capacity)
-		return OROCH_E_CAPACITY;
-	if ((rc = staged_copy(dst_host, out.p, total, false, st)))
-		return rc;
-	return staged_copy(offsets_host, offs.p, (nblocks + 1) * sizeof(uint64_t), false, st);
+	oroch_pipe *pipe = nullptr;
+	const int rc = oroch_hip::default_pipe(&pipe);
+	return rc ? rc : oroch_pipe_encode(pipe, dtype, src_host, n, dst_host, dst_capacity, offsets_host, total_host);
 }
 
 extern "C" int oroch_group_decode_host(int dtype, const void *src_host,
@@ -381,24 +361,9 @@ extern "C" int oroch_group_decode_host(int dtype, const void *src_host,
 		return OROCH_E_DTYPE;
 	if (n == 0)
 		return 0;
-	if (!src_host || !offsets_host || !dst_host)
-		return OROCH_E_ARGUMENT;
-	const size_t bytes = n << (dtype >> 1);
-	const size_t nblocks = (n + OROCH_BLOCK_VALUES - 1) / OROCH_BLOCK_VALUES;
-	const size_t total = offsets_host[nblocks];
-	dev_buf in, out, offs;
-	int rc;
-	if ((rc = in.alloc(total + 16)) || (rc = out.alloc(bytes)) ||
-	    (rc = offs.alloc((nblocks + 1) * sizeof(uint64_t))))
-		return rc;
-	hipStream_t st = nullptr;
-	if ((rc = staged_copy(in.p, src_host, total, true, st)) ||
-	    (rc = staged_copy(offs.p, offsets_host, (nblocks + 1) * sizeof(uint64_t), true, st)))
-		return rc;
-	rc = oroch_group_decode(dtype, in.p, static_cast<const uint64_t *>(offs.p), n, out.p, st);
-	if (rc)
-		return rc;
-	return staged_copy(dst_host, out.p, bytes, false, st);
+	oroch_pipe *pipe = nullptr;
+	const int rc = oroch_hip::default_pipe(&pipe);
+	return rc ? rc : oroch_pipe_decode(pipe, dtype, src_host, offsets_host, n, dst_host);
 }
 
 extern "C" int oroch_group_select_host(int dtype, const void *src_host, size_t n,

@@ -51,4 +51,22 @@ inline size_t container_stream_offset(size_t nblocks)
 // buffers; returns after the data has arrived.  (api.hip)
 int staged_copy(void *dst, const void *src, size_t bytes, bool to_device, hipStream_t st);
 
+// The pipe behind the *_host entry points of the current device, made on first
+// use.  (pipeline.hip)
+int default_pipe(oroch_pipe **out);
+
+// memcpy by a few threads (pageable <-> pinned copies are bound by one core otherwise).  (api.hip)
+void parallel_memcpy(void *dst, const void *src, size_t bytes);
+
+// Whether p is host memory the device can reach directly (hipHostMalloc,
+// hipHostRegister, torch's pin_memory): copies from and to it need no staging.
+inline bool is_pinned(const void *p)
+{
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost)
+		return true;
+	(void) hipGetLastError(); // an ordinary pointer is no error
+	return false;
+}
+
 } // namespace oroch_hip
