@@ -306,6 +306,20 @@ def main():
     dec_ms = ev[1].elapsed_time(ev[2])
 
     counts = sharding.gather_byte_counts(total, device)
+    # host to device to host: every rank drives its own GPU's pipe at the same time
+    # (after the timed region; the ranks share the host's memory bandwidth and PCIe roots)
+    e2e = None
+    if not args.no_end_to_end:
+        barrier()
+        e2e = end_to_end(x, min(n, 1 << 27))
+        if world > 1:
+            keys = ("encode_GBps", "decode_GBps", "pinned_encode_GBps", "pinned_decode_GBps")
+            mine = torch.tensor([e2e[k] for k in keys], dtype=torch.float64, device=device)
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+            for k, v in zip(keys, mine.tolist()):
+                e2e[k] = v
+            e2e["note"] = "sum over %d ranks running at the same time, one GPU and one pipe each; " % world \
+                          + e2e["note"]
     if rank == 0:
         raw = n * width  # rank 0's share; every rank holds as much (the last of a strong split maybe less)
         ms_per_step = elapsed / args.steps * 1e3
@@ -360,8 +374,8 @@ def main():
                          "encode_path": paths["encode"], "decode_path": paths["decode"]},
             "shard_bytes": counts,
         }
-        if world == 1 and not args.no_end_to_end:
-            line["end_to_end"] = end_to_end(x, min(n, 1 << 27))
+        if e2e is not None:
+            line["end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed, args.config)
         print(json.dumps(line))

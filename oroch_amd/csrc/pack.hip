@@ -195,18 +195,78 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, s
 	}
 }
 
-template <typename E, int VC>
+// The exceptions of a patched sequence as the unpacker wants them: for tile t
+// of the unpacker, first[t] is the number of the first exception at or beyond
+// the tile's first value and where[t] that exception's position (ntiles + 1
+// entries each; the last is {nexc, anything}).
+struct patch_plan
+{
+	const uint64_t *indices; // gaps, offset.h:55-60
+	const uint64_t *values;  // high parts
+	const uint64_t *first;
+	const uint64_t *where;
+	uint32_t nbits;
+};
+
+// PATCH: bitpfr.h:101-124 in one pass.  While the tile's packed words arrive,
+// the high parts of the tile's exceptions (few) are put at their values' places
+// in an array of LDS that is otherwise zero; every value takes its high part
+// from there as it is unpacked.
+template <typename E, int VC, bool PATCH = false>
 __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t n, size_t nblk,
 							 pack_geom g, typename E::C origin,
-							 typename E::S *dst)
+							 typename E::S *dst, patch_plan plan)
 {
 	using C = typename E::C;
 	using S = typename E::S;
 	constexpr int PK_VEC = 16 / E::BYTES; // values per 16-byte store
-	__shared__ __attribute__((aligned(16))) uint32_t stage[PK_MAX_BLOCKS * 4 + 4];
+	// LDS by the launch (unpack_lds_bytes): the tile's packed words, then, with
+	// PATCH, one slot per value of the tile
+	extern __shared__ __attribute__((aligned(16))) uint32_t unpack_lds[];
+	uint32_t *stage = unpack_lds;
+	C *high = reinterpret_cast<C *>(unpack_lds + g.tile_blocks * 4 + 4);
+	__shared__ uint64_t scan_lds[PK_THREADS / WAVE];
 	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
 	// (tiles start at multiples of 64 values: 16-byte stores are aligned when dst is)
 	const bool wide_ok = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0 && (g.tile_blocks * g.cap) % 64 == 0;
+	auto clear_high = [&]() {
+		// (tiles hold a multiple of 64 values)
+		for (uint32_t i = threadIdx.x * PK_VEC; i < g.tile_blocks * g.cap; i += PK_THREADS * PK_VEC)
+#pragma unroll
+			for (int t = 0; t < PK_VEC; t += int(16 / sizeof(C)))
+				*reinterpret_cast<uint4 *>(&high[i + t]) = make_uint4(0, 0, 0, 0);
+	};
+	// What a tile needs to know about its exceptions is asked for two tiles
+	// ahead (the plan) and one tile ahead (the first 64 exceptions themselves,
+	// one per lane of the first wavefront), so that no tile waits for memory
+	// more than once.
+	struct tile_plan
+	{
+		uint64_t lo = 0, hi = 0, where = 0;
+	};
+	tile_plan cur, next;
+	uint64_t ahead_step = 0;
+	C ahead_part = 0;
+	auto fetch_plan = [&](size_t t, tile_plan &tp) {
+		tp = tile_plan();
+		if (t < ntiles) {
+			tp.lo = plan.first[t];
+			tp.hi = plan.first[t + 1];
+			tp.where = plan.where[t];
+		}
+	};
+	auto fetch_entries = [&](const tile_plan &tp) {
+		const uint64_t e = tp.lo + threadIdx.x;
+		const bool take = threadIdx.x < WAVE && e < tp.hi;
+		ahead_step = take && e > tp.lo ? plan.indices[e] + 1 : 0;
+		ahead_part = take ? C(plan.values[e]) << plan.nbits : C(0);
+	};
+	if constexpr (PATCH) {
+		clear_high();
+		fetch_plan(blockIdx.x, cur);
+		fetch_plan(size_t(blockIdx.x) + gridDim.x, next);
+		fetch_entries(cur);
+	}
 	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 		const size_t b0 = tile * g.tile_blocks;
 		const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
@@ -215,6 +275,49 @@ __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t 
 		const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
 		for (uint32_t i = threadIdx.x; i < tb; i += PK_THREADS)
 			reinterpret_cast<uint4 *>(stage)[i] = src[b0 + i];
+		uint32_t mine = ~0u; // where my exception's high part went
+		bool many = false, shared_restore = false;
+		if constexpr (PATCH) {
+			const uint64_t lo = cur.lo, hi = cur.hi;
+			uint64_t pos = cur.where; // of exception lo
+			const uint64_t step = ahead_step;
+			const C part = ahead_part;
+			cur = next;
+			fetch_plan(tile + 2 * size_t(gridDim.x), next);
+			fetch_entries(cur);
+			if (hi > lo && hi - lo <= uint64_t(WAVE)) {
+				// the usual case, a few exceptions: one wavefront places them,
+				// nobody waits (its own earlier accesses to the array are in order)
+				if (threadIdx.x < WAVE) {
+					const uint64_t e = lo + threadIdx.x;
+					const uint64_t at = pos + wave_scan<uint64_t>(step, 0, [](uint64_t a, uint64_t b) { return a + b; });
+					if (e < hi && at - v0 < uint64_t(slots)) {
+						mine = uint32_t(at - v0);
+						high[mine] = part;
+					}
+				}
+			} else if (hi > lo) {
+				many = hi - lo > uint64_t(PK_THREADS);
+				shared_restore = true;
+				for (uint64_t c = lo; c < hi; c += PK_THREADS) {
+					const uint64_t e = c + threadIdx.x;
+					// steps from exception c to mine
+					const uint64_t step = e < hi && e > c ? plan.indices[e] + 1 : 0;
+					const C part = e < hi ? C(plan.values[e]) << plan.nbits : C(0);
+					uint64_t all;
+					// (the scan synchronises the workgroup: the zeros are in place)
+					const uint64_t at = pos + wg_scan_u64(step, scan_lds, &all);
+					if (e < hi && at - v0 < uint64_t(slots)) {
+						mine = uint32_t(at - v0);
+						high[mine] = part;
+					}
+					// exception c + PK_THREADS sits one more step on
+					pos += all;
+					if (c + PK_THREADS < hi)
+						pos += plan.indices[c + PK_THREADS] + 1;
+				}
+			}
+		}
 		__syncthreads();
 		if (nvals == slots && slots % PK_VEC == 0 && wide_ok) {
 			// a full tile: every lane makes 16 bytes of consecutive values per store
@@ -222,10 +325,22 @@ __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t 
 			for (uint32_t j = threadIdx.x; j < slots / PK_VEC; j += PK_THREADS) {
 				uint32_t blk = __umulhi(j * PK_VEC, g.magic);
 				uint32_t k = j * PK_VEC - blk * g.cap;
-				C v[PK_VEC];
+				C v[PK_VEC], h[PK_VEC] = {};
+				if constexpr (PATCH) {
+#pragma unroll
+					for (int t = 0; t < PK_VEC; t += int(16 / sizeof(C))) {
+						const uint4 q = *reinterpret_cast<const uint4 *>(&high[j * PK_VEC + t]);
+						if constexpr (sizeof(C) == 8) {
+							h[t] = (uint64_t(q.y) << 32) | q.x;
+							h[t + 1] = (uint64_t(q.w) << 32) | q.z;
+						} else {
+							h[t] = q.x, h[t + 1] = q.y, h[t + 2] = q.z, h[t + 3] = q.w;
+						}
+					}
+				}
 #pragma unroll
 				for (int t = 0; t < PK_VEC; t++) {
-					const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+					const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits) | h[t];
 					v[t] = value_decode<E, VC>(u, origin) & E::MASK;
 					if (++k == g.cap) {
 						k = 0;
@@ -238,11 +353,66 @@ __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t 
 			for (uint32_t i = threadIdx.x; i < nvals; i += PK_THREADS) {
 				const uint32_t blk = __umulhi(i, g.magic);
 				const uint32_t k = i - blk * g.cap;
-				const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+				C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+				if constexpr (PATCH)
+					u |= high[i];
 				dst[v0 + i] = S(value_decode<E, VC>(u, origin));
 			}
 		}
 		__syncthreads();
+		if constexpr (PATCH) {
+			// the array is all zeros again for the next tile (whose high parts
+			// go in behind a barrier of their scan)
+			if (many)
+				clear_high();
+			else if (mine != ~0u)
+				high[mine] = C(0);
+			// (zeros written by other wavefronts than the first must be in place
+			// before the first may write the next tile's parts)
+			if (shared_restore)
+				__syncthreads();
+		}
+	}
+}
+
+// Where the unpacker's tiles find their exceptions (see patch_plan): tile of
+// SCAN_TILE exceptions per workgroup; an exception that is the first at or
+// beyond the start of some tiles writes their entries, the last exception also
+// those of the tiles behind it.
+__global__ __launch_bounds__(SCAN_THREADS) void k_patch_plan(const uint64_t *indices, size_t nexc,
+							      const uint64_t *tile_base, uint64_t tile_vals,
+							      size_t ntiles, uint64_t *first, uint64_t *where)
+{
+	__shared__ uint64_t lds[SCAN_THREADS / WAVE];
+	const size_t base = size_t(blockIdx.x) * SCAN_TILE + size_t(threadIdx.x) * SCAN_ITEMS;
+	uint64_t g[SCAN_ITEMS];
+	uint64_t s = 0;
+#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; i++) {
+		g[i] = base + i < nexc ? indices[base + i] + 1 : 0;
+		s += g[i];
+	}
+	uint64_t all;
+	uint64_t run = tile_base[blockIdx.x] + wg_scan_u64(s, lds, &all) - s;
+	auto fill = [&](uint64_t from, uint64_t to, uint64_t e, uint64_t pos) {
+		// entries from .. to (inclusive); long runs (sparse exceptions) are rare
+		for (uint64_t t = from; t <= to && t <= ntiles; t++) {
+			first[t] = e;
+			where[t] = pos;
+		}
+	};
+#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; i++) {
+		if (base + i < nexc) {
+			const uint64_t pos = run + g[i] - 1;
+			const uint64_t tile = pos / tile_vals;
+			// tiles after the one of the exception before me, up to mine
+			const uint64_t after = base + i == 0 ? 0 : (run - 1) / tile_vals + 1;
+			fill(after, tile, base + i, pos);
+			if (base + i + 1 == nexc)
+				fill(tile + 1, ntiles, nexc, 0);
+		}
+		run += g[i];
 	}
 }
 
@@ -429,6 +599,15 @@ __global__ void k_store_u64(uint64_t *dst, const uint64_t *src)
 	*dst = *src;
 }
 
+// Dynamic LDS of k_unpack: the packed words of a tile (+16 bytes that a field
+// read may touch), with patches one slot of the compute type per value.
+static size_t unpack_lds_bytes(const pack_geom &g, int dtype, bool patch)
+{
+	const size_t stage = (size_t(g.tile_blocks) * 4 + 4) * sizeof(uint32_t);
+	const size_t slot = (dtype >> 1) == 3 ? 8 : 4;
+	return stage + (patch ? size_t(g.tile_blocks) * g.cap * slot + 64 : 0);
+}
+
 static unsigned pack_grid(size_t ntiles)
 {
 	const size_t cap = 256 * 8;
@@ -482,10 +661,11 @@ static int do_unpack(int dtype, const void *src, size_t n, uint64_t origin, unsi
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		profile_scope ps(OROCH_K_UNPACK, st);
-		hipLaunchKernelGGL((k_unpack<E, VC>), dim3(pack_grid(ntiles)), dim3(PK_THREADS), 0, st,
+		hipLaunchKernelGGL((k_unpack<E, VC>), dim3(pack_grid(ntiles)), dim3(PK_THREADS),
+				   unpack_lds_bytes(g, dtype, false), st,
 				   static_cast<const uint4 *>(src), n, nblk, g,
 				   typename E::C(origin & uint64_t(E::MASK)),
-				   static_cast<typename E::S *>(dst));
+				   static_cast<typename E::S *>(dst), patch_plan{});
 		return int(hipGetLastError());
 	});
 }
@@ -499,6 +679,8 @@ struct pfr_ws
 	uint64_t *total;
 	uint64_t *map;        // one bit per value, whole tiles of XT_TILE
 	size_t map_bytes;
+	uint64_t *plan_first; // per tile of the unpacker (patch_plan)
+	uint64_t *plan_where;
 	size_t bytes;
 };
 
@@ -530,6 +712,12 @@ static pfr_ws carve_pfr(void *ws, size_t n)
 	// (at most 127 values beyond n), the passes read whole tiles
 	w.map_bytes = (ntiles + 1) * (XT_TILE / 8);
 	off = up256(off + w.map_bytes);
+	// the unpacker's tiles hold 1024 values at least
+	const size_t utiles = n / 1024 + 3;
+	w.plan_first = reinterpret_cast<uint64_t *>(p + off);
+	off = up256(off + utiles * sizeof(uint64_t));
+	w.plan_where = reinterpret_cast<uint64_t *>(p + off);
+	off = up256(off + utiles * sizeof(uint64_t));
 	w.bytes = off;
 	return w;
 }
@@ -713,9 +901,44 @@ extern "C" int oroch_bitpfr_decode(int dtype, const void *src, size_t n, uint64_
 		return OROCH_E_ARGUMENT;
 	if (nexc && workspace_bytes < oroch_bitpfr_workspace(n))
 		return OROCH_E_CAPACITY;
-	int rc = do_unpack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
-	if (rc || nexc == 0)
-		return rc;
-	return oroch_bitpfr_patch(dtype, dst, n, origin, nbits, indices, values, nexc, workspace,
-				  workspace_bytes, stream);
+	if (nexc == 0 || n == 0)
+		return do_unpack<VC_ORIGIN>(dtype, src, n, origin, nbits, dst, stream);
+	if (!src || !dst || (reinterpret_cast<uintptr_t>(src) & 15u))
+		return OROCH_E_ARGUMENT;
+	// One pass over the packed words: the exceptions are sorted onto the
+	// unpacker's tiles first (a scan of their gaps), and each tile patches its
+	// own values while their packed words are still in LDS.
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	pfr_ws w = carve_pfr(workspace, n);
+	const pack_geom g = make_geom(nbits, true);
+	const size_t nblk = (n + g.cap - 1) / g.cap;
+	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
+	const uint64_t tile_vals = uint64_t(g.tile_blocks) * g.cap;
+	const size_t stiles = scan_tiles(nexc);
+	return dispatch_dtype(dtype, [&](auto e) {
+		using E = decltype(e);
+		using C = typename E::C;
+		{
+			profile_scope ps(OROCH_K_EXCEPT, st);
+			// (entries that lists with impossible gaps leave unwritten read as "no exceptions")
+			// (the two arrays are neighbours in the workspace)
+			const int r = int(hipMemsetAsync(w.plan_first, 0,
+							 size_t(reinterpret_cast<char *>(w.plan_where + ntiles + 1) -
+								reinterpret_cast<char *>(w.plan_first)), st));
+			if (r)
+				return r;
+			hipLaunchKernelGGL((k_tile_sums<uint64_t, 1>), dim3(unsigned(stiles)), dim3(SCAN_THREADS), 0, st,
+					   indices, nexc, w.tile_sums);
+			hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, st, w.tile_sums, stiles, w.total);
+			hipLaunchKernelGGL(k_patch_plan, dim3(unsigned(stiles)), dim3(SCAN_THREADS), 0, st, indices, nexc,
+					   w.tile_sums, tile_vals, ntiles, w.plan_first, w.plan_where);
+		}
+		profile_scope ps(OROCH_K_UNPACK, st);
+		const patch_plan plan = {indices, values, w.plan_first, w.plan_where, nbits};
+		hipLaunchKernelGGL((k_unpack<E, VC_ORIGIN, true>), dim3(pack_grid(ntiles)), dim3(PK_THREADS),
+				   unpack_lds_bytes(g, dtype, true), st,
+				   static_cast<const uint4 *>(src), n, nblk, g, C(origin & uint64_t(E::MASK)),
+				   static_cast<typename E::S *>(dst), plan);
+		return int(hipGetLastError());
+	});
 }
