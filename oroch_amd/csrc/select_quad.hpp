@@ -467,10 +467,13 @@ __device__ __forceinline__ void desc_words(const quad_selection &sel, uint4 &da,
 			sel.ienc | (sel.inbits << 8) | (sel.venc << 16) | (sel.vnbits << 24), 0u);
 }
 
+#ifndef SELECT_QUAD_WAVES
+#define SELECT_QUAD_WAVES 5
+#endif
 // (registers capped at what five wavefronts per SIMD allow: the kernel is
 // bound by instruction issue and the fifth wavefront fills stalls of the others)
 template <typename E>
-__global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_select_quad(const typename E::S *__restrict__ src,
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(SELECT_QUAD_WAVES, 8))) void k_select_quad(const typename E::S *__restrict__ src,
 								      size_t n, size_t nblocks,
 								      oroch_block_desc *__restrict__ desc,
 								      uint32_t *__restrict__ sizes)

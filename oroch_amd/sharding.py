@@ -96,3 +96,27 @@ def first_gap_fixup(summaries, rank, lo):
 def exception_base(summaries, rank):
     """Index of rank's first exception in the concatenated lists."""
     return sum(count for count, _ in summaries[:rank])
+
+
+def bitpfr_encode_shard(x_local, lo, origin, nbits, group=None):
+    """This rank's part of one whole-sequence bitpfr code on its GPU.
+
+    x_local: the rank's values [lo, lo + len) of the array as a CUDA tensor, lo from
+    whole_array_range.  Returns (packed words, gaps, high parts, index of the rank's
+    first exception in the concatenated lists): the shards' results put end to end, in
+    rank order, are what bitpfr_codec<T>::encode (bitpfr.h:95-99) makes of the whole
+    array.  One exchange of two numbers per rank, after the kernels.
+    """
+    from . import capi
+
+    packed, gaps, highs, count = capi.bitpfr_encode(x_local, origin, nbits)
+    last = -1
+    if count:
+        # position of my last exception: running sum of gap + 1 (offset.h:62-67)
+        last = int(lo) + int((gaps.to(torch.int64) + 1).sum().item()) - 1
+    summaries = gather_exception_summaries(count, last, x_local.device, group)
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    if count:
+        gaps = gaps.clone()
+        gaps[0] += first_gap_fixup(summaries, rank, int(lo))
+    return packed, gaps, highs, exception_base(summaries, rank)

@@ -2,6 +2,8 @@
 that do not need a CPU pass over the whole input (round trips, exception lists
 rebuilt with tensor ops, shard streams equal to slices of the whole stream),
 plus byte comparison with the oracle on a prefix of each input."""
+import os
+
 import numpy as np
 import pytest
 
@@ -157,3 +159,48 @@ def test_int16_and_uint64_host_to_device_to_host(hip, oracle):
     assert np.array_equal(stream[:want.size], want)
     back = hip.group_decode_host(stream, offs, n, np.uint64)
     assert np.array_equal(back, a)
+
+
+def _pfr_shard_worker(rank, world, port, n, nbits, outdir):
+    import torch
+    import torch.distributed as dist
+
+    import oroch_amd
+    from oroch_amd import sharding
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)  # the ranks share the one GPU of this box
+        assert oroch_amd.lib.oroch_hip_init(0) == 0
+        a = dg.outlier_mix(n, np.uint32, seed=7, body_bits=nbits, permille=3)
+        lo, hi = sharding.whole_array_range(n, rank, world, nbits)
+        x = torch.from_numpy(a[lo:hi].view(np.int32)).cuda().view(torch.uint32)
+        packed, gaps, highs, base = sharding.bitpfr_encode_shard(x, lo, 0, nbits)
+        np.savez(os.path.join(outdir, "gpfr%d.npz" % rank), packed=packed.cpu().numpy(),
+                 gaps=gaps.cpu().numpy().astype(np.uint64), highs=highs.cpu().numpy().astype(np.uint64),
+                 base=np.uint64(base))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_whole_array_bitpfr_sharded_on_the_gpu(hip, oracle, tmp_path, world):
+    """Config 3 on more than one GPU: every rank packs its word-aligned range with
+    the HIP kernels, two numbers per rank are exchanged, and the shards end to end
+    are the oracle's code of the whole array (ranks share this box's one GPU)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    n, nbits = 300007, 10
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_pfr_shard_worker, args=(world, port, n, nbits, str(tmp_path)), nprocs=world, join=True)
+    a = dg.outlier_mix(n, np.uint32, seed=7, body_bits=nbits, permille=3)
+    want_packed, want_gaps, want_highs = oracle.bitpfr_encode(a, 0, nbits)
+    parts = [np.load(os.path.join(str(tmp_path), "gpfr%d.npz" % r)) for r in range(world)]
+    assert [int(p["base"]) for p in parts] == list(np.cumsum([0] + [p["gaps"].size for p in parts[:-1]]))
+    assert np.array_equal(np.concatenate([p["packed"] for p in parts]), want_packed)
+    assert np.array_equal(np.concatenate([p["gaps"] for p in parts]), want_gaps)
+    assert np.array_equal(np.concatenate([p["highs"] for p in parts]), want_highs)
