@@ -979,20 +979,28 @@ static int insert_value(oroch_array *a, uint64_t index, uint64_t value)
 	    (rc = int(hipMemcpy(mv + (at + 1) * w, v + at * w, (cnt - at) * w, hipMemcpyDeviceToDevice))) ||
 	    (rc = int(hipMemcpy(last, mv + cnt * w, w, hipMemcpyDeviceToHost))))
 		return rc;
-	// room for the new images first, so that a failed allocation leaves the
-	// array as it was
-	if ((rc = grow(a->stream, a->stream_cap, size_t(cut) + oroch_group_bound(a->dtype, cnt), a->stream_bytes)))
+	// The new images are made beside the old ones and take their place only when
+	// everything that can fail has succeeded: a failure on the way leaves the
+	// array as it was.
+	const size_t nb = cnt / BLOCK;
+	const size_t bound = oroch_group_bound(a->dtype, cnt), wsb = oroch_group_workspace(a->dtype, cnt);
+	dev_buf images, piece, ws;
+	uint64_t total = 0;
+	if ((rc = images.alloc(bound)) || (rc = piece.alloc((nb + 1) * sizeof(uint64_t))) || (rc = ws.alloc(wsb)) ||
+	    (rc = oroch_group_encode(a->dtype, mv, cnt, images.p, bound, static_cast<uint64_t *>(piece.p), ws.p, wsb,
+				     &total, nullptr)) ||
+	    (rc = grow(a->stream, a->stream_cap, size_t(cut) + size_t(total) + 16, a->stream_bytes)))
 		return rc;
-	const size_t old_blocks = a->nblocks, old_bytes = a->stream_bytes;
-	a->nblocks = g;
-	a->stream_bytes = size_t(cut);
-	if ((rc = encode_blocks(a, mv, cnt))) {
-		if (a->nblocks == g) {
-			a->nblocks = old_blocks;
-			a->stream_bytes = old_bytes;
-		}
+	a->tail.reserve(a->tail.size() + w); // may throw, before anything has changed
+	const unsigned grid = unsigned((nb + 1 + 255) / 256 < 1024 ? (nb + 1 + 255) / 256 : 1024);
+	if ((rc = int(hipMemcpy(static_cast<uint8_t *>(a->stream.p) + cut, images.p, size_t(total),
+				hipMemcpyDeviceToDevice))))
 		return rc;
-	}
+	hipLaunchKernelGGL(k_rebase, dim3(grid), dim3(256), 0, nullptr, static_cast<const uint64_t *>(piece.p), nb + 1,
+			   cut, static_cast<uint64_t *>(a->offsets.p) + g);
+	if ((rc = int(hipGetLastError())) || (rc = int(hipStreamSynchronize(nullptr))))
+		return rc;
+	a->stream_bytes = size_t(cut) + size_t(total);
 	a->tail.insert(a->tail.begin(), last, last + w);
 	return flush_tail(a);
 }
