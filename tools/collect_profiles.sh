@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collects what profiles/ holds for a round, on the GPU box:
+#   tools/collect_profiles.sh <tag, e.g. r2_a> <commit the kernels were built from>
+# 1. rocprofv3 kernel statistics and the bench line of the headline (int32, 2^30 values)
+# 2. HBM traffic of the same kernels from two counter passes (FETCH_SIZE, WRITE_SIZE), each a run of its own
+# 3. kernel statistics of the int64 block mix (2^30 values), of int16 and of uint64 inputs
+# Summaries go to gpurun_out/<tag>/; copy them into profiles/ afterwards.
+set -e
+TAG=$1
+COMMIT=$2
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+stats() { # <name> <program and arguments ...>
+	local name=$1; shift
+	timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw_$name -o p -- "$@" > $OUT/${name}.log 2>&1
+	local f=$(find $OUT/raw_$name -name "*kernel_stats.csv" | head -n 1)
+	(head -n 1 $f; grep oroch_hip $f) > $OUT/${TAG}_${name}_kernel_stats.csv
+}
+stats headline python3 $R/bench.py --steps 20 --no-cpu-baseline --no-end-to-end
+grep '^{' $OUT/headline.log | tail -n 1 > $OUT/${TAG}_bench.json
+for c in FETCH_SIZE WRITE_SIZE; do
+	timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $OUT/pmc_$c.log 2>&1
+done
+python3 $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $COMMIT > $OUT/traffic_int32_2p30.json
+stats int64mix python3 $R/bench.py --config int64mix --steps 10 --no-cpu-baseline --no-end-to-end
+grep '^{' $OUT/int64mix.log | tail -n 1 > $OUT/${TAG}_int64mix_bench.json
+DT=int16 KIND=outlier BODY=9 OUT=15 LOG2N=29 stats int16 python3 $R/tools/time_any.py
+DT=uint64 KIND=outlier BODY=20 OUT=50 LOG2N=28 stats uint64 python3 $R/tools/time_any.py
+DT=int32 KIND=uniform BODY=13 LOG2N=28 stats int32_uniform13 python3 $R/tools/time_any.py
+stats sequences python3 $R/tools/time_sequences.py
+grep -h "frac of 8TB/s\|of 8 TB/s" $OUT/int16.log $OUT/uint64.log $OUT/int32_uniform13.log $OUT/sequences.log > $OUT/${TAG}_other_inputs.txt
+ls -la $OUT

@@ -2,7 +2,7 @@
 """HBM traffic per launch of the block kernels from two rocprofv3 --pmc passes
 (FETCH_SIZE and WRITE_SIZE, each collected in a run of its own).
 
-    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> > profiles/traffic.json
+    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [commit] > profiles/traffic.json
 
 Both counters are in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests
 of wide streaming reads at 64 bytes, so it is doubled; WRITE_SIZE is exact for
@@ -16,7 +16,7 @@ import sys
 
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/**/*counter_collection.csv", recursive=True))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter or "oroch" not in r["Kernel_Name"]:
@@ -26,7 +26,7 @@ def load(d, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
-def main(fetch_dir, write_dir):
+def main(fetch_dir, write_dir, commit=None):
     fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
@@ -34,9 +34,9 @@ def main(fetch_dir, write_dir):
         wr = 1024.0 * write.get(k, 0.0)
         out[k] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
     json.dump({"unit": "bytes per launch", "correction": "FETCH_SIZE x 2 (gfx950), KiB -> bytes",
-               "kernels": out}, sys.stdout, indent=1)
+               "commit": commit, "kernels": out}, sys.stdout, indent=1)
     print()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

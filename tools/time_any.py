@@ -9,13 +9,16 @@ log2n = int(os.environ.get("LOG2N", "27"))
 kind = os.environ.get("KIND", "outlier")
 n = 1 << log2n
 dev = torch.device("cuda", 0)
-tdt = getattr(torch, dt)
+unsigned64 = dt == "uint64"  # generated as int64 bit patterns, handed over as uint64
+tdt = getattr(torch, "int64" if unsigned64 else dt)
 if kind == "outlier":
     x = devgen.outlier_mix(n, tdt, 3, dev, body_bits=int(os.environ.get("BODY", "10")), out_bits=int(os.environ.get("OUT", "28")), shift=-200)
 elif kind == "mix":
     x = devgen.block_mix_int64(n, 4, dev).to(tdt)
 else:
     x = devgen.uniform_bits(n, tdt, 3, int(os.environ.get("BODY", "13")), dev)
+if unsigned64:
+    x = (x + (1 << 40)).view(torch.uint64)
 enc = oroch_amd.GroupEncoder(x.dtype, n, x.device)
 back = torch.empty_like(x)
 code = oroch_amd.dtype_code(x.dtype)
@@ -31,4 +34,4 @@ total = int(enc.offsets[-1].item())
 raw = n * x.element_size()
 res = {k: round(ms / c, 4) for k, (ms, c) in p.items()}
 fr = {k: round((raw + (total if k != "select" else 0)) / (v * 1e-3) / 8e12, 3) for k, v in res.items() if k != "scan"}
-print(dt, kind, "n=2^%d" % log2n, "ratio %.3f" % (total / raw), "ms:", json.dumps(res), "frac of 8TB/s:", json.dumps(fr), "ok" if torch.equal(back, x) else "MISMATCH")
+print(dt, kind, "n=2^%d" % log2n, "ratio %.3f" % (total / raw), "ms:", json.dumps(res), "frac of 8TB/s:", json.dumps(fr), "ok" if torch.equal(back.view(torch.uint8), x.view(torch.uint8)) else "MISMATCH")
