@@ -9,26 +9,26 @@ set -e
 TAG=$1
 COMMIT=$2
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/$TAG
-mkdir -p $OUT
+DEST=$R/gpurun_out/$TAG
+mkdir -p $DEST
 cd /tmp && export TMPDIR=/tmp
 stats() { # <name> <program and arguments ...>
 	local name=$1; shift
-	timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw_$name -o p -- "$@" > $OUT/${name}.log 2>&1
-	local f=$(find $OUT/raw_$name -name "*kernel_stats.csv" | head -n 1)
-	(head -n 1 $f; grep oroch_hip $f) > $OUT/${TAG}_${name}_kernel_stats.csv
+	timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $DEST/raw_$name -o p -- "$@" > $DEST/${name}.log 2>&1
+	local f=$(find $DEST/raw_$name -name "*kernel_stats.csv" | head -n 1)
+	(head -n 1 $f; grep oroch_hip $f) > $DEST/${TAG}_${name}_kernel_stats.csv
 }
 stats headline python3 $R/bench.py --steps 20 --no-cpu-baseline --no-end-to-end
-grep '^{' $OUT/headline.log | tail -n 1 > $OUT/${TAG}_bench.json
+grep '^{' $DEST/headline.log | tail -n 1 > $DEST/${TAG}_bench.json
 for c in FETCH_SIZE WRITE_SIZE; do
-	timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $OUT/pmc_$c.log 2>&1
+	timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d $DEST/pmc_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $DEST/pmc_$c.log 2>&1
 done
-python3 $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $COMMIT > $OUT/traffic_int32_2p30.json
+python3 $R/tools/pmc_traffic.py $DEST/pmc_FETCH_SIZE $DEST/pmc_WRITE_SIZE $COMMIT > $DEST/traffic_int32_2p30.json
 stats int64mix python3 $R/bench.py --config int64mix --steps 10 --no-cpu-baseline --no-end-to-end
-grep '^{' $OUT/int64mix.log | tail -n 1 > $OUT/${TAG}_int64mix_bench.json
+grep '^{' $DEST/int64mix.log | tail -n 1 > $DEST/${TAG}_int64mix_bench.json
 DT=int16 KIND=outlier BODY=9 OUT=15 LOG2N=29 stats int16 python3 $R/tools/time_any.py
 DT=uint64 KIND=outlier BODY=20 OUT=50 LOG2N=28 stats uint64 python3 $R/tools/time_any.py
 DT=int32 KIND=uniform BODY=13 LOG2N=28 stats int32_uniform13 python3 $R/tools/time_any.py
 stats sequences python3 $R/tools/time_sequences.py
-grep -h "frac of 8TB/s\|of 8 TB/s" $OUT/int16.log $OUT/uint64.log $OUT/int32_uniform13.log $OUT/sequences.log > $OUT/${TAG}_other_inputs.txt
-ls -la $OUT
+grep -h "frac of 8TB/s\|of 8 TB/s" $DEST/int16.log $DEST/uint64.log $DEST/int32_uniform13.log $DEST/sequences.log > $DEST/${TAG}_other_inputs.txt
+ls -la $DEST
