@@ -312,7 +312,6 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_at(const uint8_t *__rest
 	constexpr int NCH = int((MAXLEN + 1023) / 1024);
 	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
 	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK + FIELDS_PAD];
-	__shared__ __attribute__((aligned(16))) C highs[WAVES_PER_WG][BLOCK];
 	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
 	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
@@ -362,9 +361,9 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_at(const uint8_t *__rest
 			wave_sync();
 			C v[VPL];
 			if (bnv == BLOCK)
-				decode_block<E, true>(img, blen, bnv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+				decode_block<E, true>(img, blen, bnv, lane, vals[wave], gaps[wave], wt, v);
 			else
-				decode_block<E, false>(img, blen, bnv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+				decode_block<E, false>(img, blen, bnv, lane, vals[wave], gaps[wave], wt, v);
 			if (uint32_t(lane) == bpos / VPL) {
 				const uint32_t s = bpos % VPL;
 				const C x = s == 0 ? v[0] : s == 1 ? v[1] : s == 2 ? v[2] : v[3];

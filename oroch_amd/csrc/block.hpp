@@ -132,9 +132,15 @@ __device__ __forceinline__ uint64_t get_varint(const uint8_t *img, uint32_t &pos
 // working on 64 bytes at a time: a byte that ends a value (top bit clear)
 // closes one; every byte ORs its 7 payload bits into its value's slot of
 // `out` (LDS, zero filled by the caller).  Returns the bytes consumed.
+//
+// With `where` (LDS, one entry per value) value number i goes to
+// out[where[i]] instead of out[i], shifted up by `shift` bits, and entries of
+// `where` at or beyond `slots` are left out: the high parts of a patched
+// block, OR-ed straight into the values they belong to.
 template <typename C>
 __device__ uint32_t varint_list_decode(const uint8_t *img8, uint32_t start, uint32_t limit,
-				       uint32_t count, C *out, int lane)
+				       uint32_t count, C *out, int lane, const uint32_t *where = nullptr,
+				       uint32_t shift = 0, uint32_t slots = 0)
 {
 	uint32_t done = 0;   // values completed so far
 	uint32_t carry = 0;  // bytes of the open value seen in earlier chunks
@@ -149,14 +155,15 @@ __device__ uint32_t varint_list_decode(const uint8_t *img8, uint32_t start, uint
 		const int pt = below ? 63 - __clzll(below) : -1;
 		const uint32_t k = uint32_t(lane - pt - 1) + (pt < 0 ? carry : 0u);
 		const uint32_t vi = done + r;
-		if (vi < count && k * 7u < sizeof(C) * 8u) {
-			C part = C(byte & 0x7fu) << (k * 7u);
-			if (part) {
+		if (vi < count && k * 7u + shift < sizeof(C) * 8u) {
+			C part = C(byte & 0x7fu) << (k * 7u + shift);
+			const uint32_t to = where ? where[vi] : vi;
+			if (part && (!where || to < slots)) {
 				if constexpr (sizeof(C) == 8)
-					atomicOr(reinterpret_cast<unsigned long long *>(&out[vi]),
+					atomicOr(reinterpret_cast<unsigned long long *>(&out[to]),
 						 (unsigned long long) part);
 				else
-					atomicOr(&out[vi], part);
+					atomicOr(&out[to], part);
 			}
 		}
 		// how far does this chunk go: up to the terminator that completes
@@ -210,7 +217,7 @@ __device__ __forceinline__ uint64_t hdr_varint(uint64_t h0, uint64_t h1, uint32_
 // Decodes the block whose image (len bytes) sits in `img`.  FULL: 256 values.
 template <typename E, bool FULL>
 __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv, int lane, typename E::C *val,
-			     typename E::C *hv, uint32_t *gp, const uint4 *wt, typename E::C (&v)[VPL])
+			     uint32_t *gp, const uint4 *wt, typename E::C (&v)[VPL])
 {
 	using C = typename E::C;
 	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
@@ -287,19 +294,15 @@ __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv
 		    inb <= 64) {
 			// integer_codec.h:583-609, bitpfr.h:114-124
 			const uint32_t ibase = doff + pck_space(wt, uint32_t(nv), nb);
-			// varint lists are assembled by OR into zeroed LDS slots
-			if (!inb || !vnb) {
-				for (uint32_t i = uint32_t(lane); i < nout; i += WAVE) {
-					hv[i] = 0;
+			// a varint list of gaps is assembled by OR into zeroed LDS slots
+			if (!inb) {
+				for (uint32_t i = uint32_t(lane); i < nout; i += WAVE)
 					gp[i] = 0;
-				}
 				wave_sync();
 			}
 			const uint32_t ilen = inb ? pck_space(wt, nout, inb)
 						  : varint_list_decode<uint32_t>(img8, ibase, len, nout, gp, lane);
 			const uint32_t vbase = ibase + ilen;
-			if (!vnb)
-				varint_list_decode<C>(img8, vbase, len, nout, hv, lane);
 			const uint4 iw = wt[inb ? inb : 1u], vw = wt[vnb ? vnb : 1u];
 			const uint32_t icap = uniform(iw.x), imagic = uniform(iw.y);
 			const uint32_t vcap = uniform(vw.x), vmagic = uniform(vw.y);
@@ -323,18 +326,25 @@ __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv
 					}
 					const uint32_t incl = wave_scan_sum(step, lane) + carry;
 					carry = read_lane(incl, WAVE - 1);
-					if (e < nout && incl - 1u < uint32_t(BLOCK)) {
-						C hi;
+					if (e < nout) {
 						if (vnb) {
-							const uint32_t bk = __umulhi(e, vmagic);
-							hi = lds_get_bits<C>(img, vbase * 8u + bk * 128u + (e - bk * vcap) * vnb,
-									     vnb);
+							if (incl - 1u < uint32_t(BLOCK)) {
+								const uint32_t bk = __umulhi(e, vmagic);
+								const C hi = lds_get_bits<C>(
+									img, vbase * 8u + bk * 128u + (e - bk * vcap) * vnb, vnb);
+								val[incl - 1u] |= C(hi << nb) & E::MASK;
+							}
 						} else {
-							hi = hv[e];
+							gp[e] = incl - 1u; // where the e-th high part goes
 						}
-						val[incl - 1u] |= C(hi << nb) & E::MASK;
 					}
 				}
+			}
+			if (!vnb) {
+				// a varint list of high parts: every byte ORs its bits into the
+				// value of its exception
+				wave_sync();
+				varint_list_decode<C>(img8, vbase, len, nout, val, lane, gp, nb, uint32_t(BLOCK));
 			}
 			wave_sync();
 		}
@@ -387,7 +397,6 @@ __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 	// image: the block's bytes; vals: one slot per value (list scratch, patches)
 	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
 	__shared__ __attribute__((aligned(16))) C vals[WAVES_PER_WG][BLOCK + FIELDS_PAD];
-	__shared__ __attribute__((aligned(16))) C highs[WAVES_PER_WG][BLOCK];
 	__shared__ __attribute__((aligned(16))) uint32_t gaps[WAVES_PER_WG][BLOCK];
 	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
@@ -460,9 +469,9 @@ __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 		if (w == WALK_DECODE) {
 			C v[VPL];
 			if (nv == BLOCK)
-				decode_block<E, true>(img, len0, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+				decode_block<E, true>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
 			else
-				decode_block<E, false>(img, len0, nv, lane, vals[wave], highs[wave], gaps[wave], wt, v);
+				decode_block<E, false>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
 			sink(blk, nv, v);
 		}
 		wave_sync();

@@ -381,9 +381,10 @@ __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 	constexpr int NCH = int((QBYTES + 1023) / 1024);
 	constexpr int NPRE = NCH < 3 ? NCH : 3;
 	__shared__ __attribute__((aligned(16))) uint32_t qbufs[WAVES_PER_WG][QBYTES / 4 + 24];
-	// value slots of two blocks; the one-block path needs a little more
-	constexpr int SLOTS = SLOT_STRIDE + 2 * BLOCK;
-	static_assert(SLOTS >= 2 * SLOT_STRIDE, "two blocks of slots");
+	// value slots of two blocks; the one-block path takes one block of slots and
+	// one of list positions
+	constexpr int SLOTS = 2 * SLOT_STRIDE;
+	static_assert(SLOTS >= SLOT_STRIDE + BLOCK, "slots and positions of one block");
 	__shared__ __attribute__((aligned(16))) C slotss[WAVES_PER_WG][SLOTS];
 	__shared__ __attribute__((aligned(16))) uint8_t endss[WAVES_PER_WG][QUAD * ENDS];
 	__shared__ uint4 wt[65];
@@ -472,12 +473,12 @@ __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 				const int nv = block_count(n, blk0 + size_t(b));
 				C v[VPL];
 				uint32_t *img = qbuf + (at >> 2);
-				C *val = slots, *hv = slots + SLOT_STRIDE;
-				uint32_t *gp = reinterpret_cast<uint32_t *>(slots + SLOT_STRIDE + BLOCK);
+				C *val = slots;
+				uint32_t *gp = reinterpret_cast<uint32_t *>(slots + SLOT_STRIDE);
 				if (nv == BLOCK)
-					decode_block<E, true>(img, len, nv, lane, val, hv, gp, wt, v);
+					decode_block<E, true>(img, len, nv, lane, val, gp, wt, v);
 				else
-					decode_block<E, false>(img, len, nv, lane, val, hv, gp, wt, v);
+					decode_block<E, false>(img, len, nv, lane, val, gp, wt, v);
 				sink(blk0 + size_t(b), nv, lane, v);
 				wave_sync();
 			}

@@ -133,11 +133,7 @@ __device__ __forceinline__ uint32_t fq_encode(const typename E::C (&v)[VPQ], con
 	const uint32_t ienc = db.z & 0xffu, inb = (db.z >> 8) & 0xffu;
 	const uint32_t venc = (db.z >> 16) & 0xffu, vnb = db.z >> 24;
 	const uint32_t doff = (metaspace + 7u) & ~7u; // integer_group.h:50-52
-#ifdef FQ_X_ONLY10 // experiment: one width's code only
-	const bool width_ok = nb == 10u;
-#else
 	const bool width_ok = nb >= uint32_t(FIELDS_MIN_NB) && nb <= uint32_t(E::W);
-#endif
 	const uint32_t pck = wt[width_ok ? nb : 1u].w;
 	const uint32_t list_at = doff + pck;
 	const bool ok = (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) && width_ok &&
@@ -193,11 +189,7 @@ __device__ __forceinline__ uint32_t fq_encode(const typename E::C (&v)[VPQ], con
 	for (uint32_t left = fast; left;) {
 		const uint32_t nb_u = read_lane(nb, int(__builtin_ctz(left)) * GROUP);
 		const uint32_t cls = group_mask(__ballot(ok && nb == nb_u));
-#ifdef FQ_X_ONLY10
-		fq_pack_dispatch<E, 10, 10>(nb_u, make_class(cls), slots, rel + doff, lane, img);
-#else
 		fq_pack_dispatch<E, FIELDS_MIN_NB, E::W>(nb_u, make_class(cls), slots, rel + doff, lane, img);
-#endif
 		left &= ~cls;
 	}
 
@@ -420,11 +412,6 @@ __device__ __forceinline__ void fq_exchange(const fq_state &st, fq_mail *mail, u
 			}
 			uint32_t before = 0;
 			ok = ok && (group == 0 || fq_row_sum(cur, group, lane, before));
-#ifdef FQ_EXPERIMENT_NO_WAIT // timing only: wrong offsets, no waiting
-			ok = true;
-			base = 0;
-			before = (r * groups + group) * FQ_WORKERS * 100u;
-#endif
 			if (ok) {
 				if (lane == 0)
 					mail->base[r % uint32_t(FQ_QDEPTH)] = base + (uint64_t(before) << 4);
@@ -530,10 +517,8 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 			base += uniform(mail.bytes[slot][w]);
 		const uint32_t pos = uniform(queue[slot][0]), total = uniform(queue[slot][1]);
 		const uint32_t s0 = uniform(queue[slot][2]), s1 = uniform(queue[slot][3]), s2 = uniform(queue[slot][4]);
-#ifndef FQ_X_NOCOPY
 		for (uint32_t o = uint32_t(lane) * 16u; o < total; o += WAVE * 16u)
 			*reinterpret_cast<uint4 *>(dst + base + o) = *reinterpret_cast<const uint4 *>(ring + pos + o);
-#endif
 		const size_t b0 = t * QUAD;
 		const uint32_t rel = lane == 0 ? 0u : lane == 1 ? s0 : lane == 2 ? s0 + s1 : s0 + s1 + s2;
 		if (lane < QUAD && b0 + size_t(lane) < nblocks)
@@ -647,10 +632,8 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 				const uint32_t sum16 = (old & 0xffffffu) + (total >> 4);
 				if (lane == 0) {
 					mail.arrived[slot] = 0;
-#ifndef FQ_X_NOPUBLISH
 					__hip_atomic_store(&st.rows[size_t(r) * FQ_MAX_GROUPS + group], uint16_t(FQ_ROW_VALID | sum16),
 							   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 				}
 				fq_lds_store(&mail.published, r + 1u);
 			}
@@ -666,12 +649,8 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 		FQ_TIME(3, lane, t_mid);
 		const uint64_t t_enc = FQ_NOW();
 		uint32_t done = 0;
-#ifdef FQ_X_NOENCODE
-		done = 15u;
-#else
 		if (whole)
 			done = fq_encode<E>(v, da, db, rel, lane, slots, wt, img);
-#endif
 		if (done != 15u) {
 			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
 				if ((done >> b) & 1u)
