@@ -415,20 +415,16 @@ __device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *h
 	const uint32_t fixed = basic_meta + xmeta + lc.pck256 + vdata;
 	const uint32_t est = fixed + indmin;
 
-	uint64_t cand = __ballot(active && est < best);
-	while (cand) {
-		const int L = __builtin_ctzll(cand);
-		cand &= cand - 1;
-		if (read_lane(est, L) >= best)
-			continue;
+	// What width bL = L + 1 needs once its index list is known (:338-351).
+	auto evaluate = [&](int L, uint32_t &required, uint32_t &ienc, uint32_t &indnbits) {
 		const uint32_t bL = uint32_t(L) + 1;
 		const uint32_t noutL = read_lane(nout, L);
-		uint32_t indnbits, indvar;
+		uint32_t indvar;
 		if (noutL >= BLOCK - 1) {
 			indnbits = 1;
 			indvar = noutL;
 		} else {
-			// last exception at or before each lane, then the gaps, :338-351
+			// last exception at or before each lane, then the gaps
 			bool f[VPL];
 #pragma unroll
 			for (int s = 0; s < VPL; s++)
@@ -462,23 +458,63 @@ __device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *h
 			const uint4 ci = wt[indnbits];
 			indpck = 16u * __umulhi(noutL + uniform(ci.x) - 1u, uniform(ci.y));
 		}
-		const uint32_t ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
+		ienc = indpck < indvar ? OROCH_BITPCK : OROCH_VARINT;
 		const uint32_t idata = indpck < indvar ? indpck : indvar;
-		const uint32_t required = read_lane(fixed, L) + idata;
-		if (required < best) {
-			best = required;
-			const uint32_t xm = read_lane(xmeta, L);
-			sel.encoding = OROCH_BITPFR;
-			sel.origin = mn;
-			sel.nbits = bL;
-			sel.noutliers = noutL;
-			sel.venc = read_lane(venc, L);
-			sel.vnbits = nbmax - bL;
-			sel.ienc = ienc;
-			sel.inbits = ienc == OROCH_BITPCK ? indnbits : 0u;
-			sel.metaspace = 1 + basic_meta + xm;
-			sel.dataspace = required - basic_meta - xm;
+		required = read_lane(fixed, L) + idata;
+	};
+	auto adopt = [&](int L, uint32_t required, uint32_t ienc, uint32_t indnbits) {
+		best = required;
+		const uint32_t xm = read_lane(xmeta, L);
+		sel.encoding = OROCH_BITPFR;
+		sel.origin = mn;
+		sel.nbits = uint32_t(L) + 1;
+		sel.noutliers = read_lane(nout, L);
+		sel.venc = read_lane(venc, L);
+		sel.vnbits = nbmax - uint32_t(L) - 1;
+		sel.ienc = ienc;
+		sel.inbits = ienc == OROCH_BITPCK ? indnbits : 0u;
+		sel.metaspace = 1 + basic_meta + xm;
+		sel.dataspace = required - basic_meta - xm;
+	};
+
+	// The reference walks the widths upwards, looks at one when its estimate is
+	// below the best total so far (:327-335) and adopts it when its real need is
+	// below that too.  One evaluation replaces the walk when the width with the
+	// lowest lower bound (its index list at its shortest: one byte per exception
+	// or the one-bit packing) comes out, estimate and real need, below every
+	// other candidate's lower bound and below the best basic encoding: nothing
+	// before it can then have hidden it, nothing after it can beat it.
+	const bool c0 = active && est < best;
+	uint64_t cand = __ballot(c0);
+	if (cand == 0)
+		return;
+	const uint32_t low = fixed + (nout < indmin ? nout : indmin);
+	const uint32_t key = c0 ? (low << 6) | uint32_t(lane) : ~0u;
+	const uint32_t first = wave_min(key);
+	const uint32_t second = wave_min(key == first ? ~0u : key);
+	const int L1 = int(first & 63u);
+	uint32_t required1, ienc1, indnbits1;
+	evaluate(L1, required1, ienc1, indnbits1);
+	{
+		const uint32_t estL = read_lane(est, L1);
+		const uint32_t top = required1 > estL ? required1 : estL;
+		const uint32_t bound = best < (second >> 6) ? best : (second >> 6);
+		if (top < bound) {
+			adopt(L1, required1, ienc1, indnbits1);
+			return;
 		}
+	}
+	// the walk itself; what is known of width L1 + 1 is used again
+	while (cand) {
+		const int L = __builtin_ctzll(cand);
+		cand &= cand - 1;
+		if (read_lane(est, L) >= best)
+			continue;
+		uint32_t required = required1, ienc = ienc1, indnbits = indnbits1;
+		if (L != L1)
+			evaluate(L, required, ienc, indnbits);
+		if (required < best)
+			adopt(L, required, ienc, indnbits);
 	}
 }
 
