@@ -319,10 +319,13 @@ __device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *h
 	const C mn = wave_min(kmin) ^ E::FLIP;
 	const uint32_t vo = vsp(zz<E>(mn));
 
-	// Bin k of the table is four dwords, one per lane & 3, each holding the
-	// delta count in its low half and the zigzag count in its high half: the
-	// copies cut same-address serialisation of the LDS atomics by four.
+	// Bin k of the table is four dwords, one per lane & 3: the copies cut
+	// same-address serialisation of the LDS atomics by four.  The zigzag images
+	// need no histogram: selection wants the sum of their varint lengths
+	// (ceil(L / 7) = (37 L + 219) >> 8 for a bit length L of 1..64; zero takes
+	// one byte like L = 1) and the longest of them.
 	uint32_t ud[VPL];
+	uint32_t zbytes = 0, zlong = 1;
 	*reinterpret_cast<uint4 *>(&hq[lane * 4]) = make_uint4(0, 0, 0, 0);
 	if (lane == 0)
 		*reinterpret_cast<uint4 *>(&hq[256]) = make_uint4(0, 0, 0, 0);
@@ -332,15 +335,18 @@ __device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *h
 	for (int s = 0; s < VPL; s++) {
 		ud[s] = bitlen(C((v[s] - mn) & E::MASK));
 		atomicAdd(&mine[ud[s] * 4], 1u);
-		atomicAdd(&mine[bitlen(zz<E>(v[s])) * 4], 0x10000u);
+		uint32_t zl = bitlen(zz<E>(v[s]));
+		zl = zl ? zl : 1u;
+		zbytes += (37u * zl + 219u) >> 8;
+		zlong = zl > zlong ? zl : zlong;
 	}
 	wave_sync();
 	const uint4 q = *reinterpret_cast<const uint4 *>(&hq[(lane + 1) * 4]);
 	const uint4 q0 = *reinterpret_cast<const uint4 *>(&hq[0]);
 	wave_sync();
 	const uint32_t qs = q.x + q.y + q.z + q.w, q0s = uniform(q0.x + q0.y + q0.z + q0.w);
-	const uint2 h = make_uint2(qs & 0xffffu, qs >> 16);
-	const uint32_t zero_d = q0s & 0xffffu, zero_z = q0s >> 16;
+	const uint2 h = make_uint2(qs, 0);
+	const uint32_t zero_d = q0s;
 
 	// integer_codec.h:255-264
 	if (zero_d == BLOCK) {
@@ -350,11 +356,10 @@ __device__ void select_full(const typename E::C (&v)[VPL], int lane, uint32_t *h
 		return;
 	}
 
-	const uint32_t t = wave_sum(h.x * lc.w + ((h.y * lc.w) << 16));
-	const uint32_t vfs = (t & 0xffffu) + zero_d, vis = (t >> 16) + zero_z;
+	const uint32_t t = wave_sum(h.x * lc.w + (zbytes << 16));
+	const uint32_t vfs = (t & 0xffffu) + zero_d, vis = t >> 16;
 	const uint32_t nbmax = 64u - uint32_t(__builtin_clzll(__ballot(h.x != 0)));
-	const uint64_t zbins = __ballot(h.y != 0);
-	const uint32_t nbz = zbins ? 64u - uint32_t(__builtin_clzll(zbins)) : 1u;
+	const uint32_t nbz = wave_max(zlong);
 
 	// select_basic, integer_codec.h:422-496
 	uint32_t best = BLOCK * E::BYTES, bmeta0 = 0;
