@@ -308,7 +308,7 @@ struct fq_mail
 {
 	uint32_t bytes[FQ_QDEPTH][FQ_WORKERS];  // size of each worker's tile (the worker writes)
 	uint32_t arrived[FQ_QDEPTH];            // workers that have written theirs << 24 | sum of sizes / 16
-	uint64_t base[FQ_QDEPTH];               // offset of the first worker's tile (the exchanger writes)
+	uint64_t base[FQ_QDEPTH][FQ_WORKERS];   // offset of each worker's tile (the exchanger writes)
 	uint32_t published;                     // rounds whose row entry has been stored
 	uint32_t resolved;                      // rounds whose offset is in `base`
 	uint32_t abort;                         // the launch has been given up
@@ -368,6 +368,31 @@ __device__ __forceinline__ bool fq_row_sum(uint64_t x, uint32_t count, int lane,
 	return true;
 }
 
+// An exchanger whose wait has run out: the launch is given up (the abort word is
+// set, the workgroup's workers are told), and the first exchanger to do so leaves
+// behind, in the words after the abort word, where it stood: workgroup, round,
+// which wait (1: its own workers' sizes, 2: the table), complete rows, rounds
+// published and resolved, and the arrival words of the mail.
+__device__ __forceinline__ void fq_give_up(const fq_state &st, fq_mail *mail, uint32_t group, uint32_t r, uint32_t wait,
+					   uint32_t rows_done, int lane)
+{
+	if (lane == 0) {
+		const uint32_t was = atomicCAS(st.abort_flag, 0u, 1u);
+		if (was == 0) {
+			uint32_t *note = st.abort_flag + 1;
+			note[0] = group;
+			note[1] = r;
+			note[2] = wait;
+			note[3] = rows_done;
+			note[4] = mail->published;
+			note[5] = mail->resolved;
+			for (int i = 0; i < FQ_QDEPTH; i++)
+				note[6 + i] = mail->arrived[i];
+		}
+	}
+	fq_lds_store(&mail->abort, 1u);
+}
+
 // The exchanger's loop: for every round of the workgroup, once the workgroup's
 // own entry is in the table, polls the table until the entries before it are
 // there, and hands the offset to the workers.  Loads only.
@@ -382,9 +407,7 @@ __device__ __forceinline__ void fq_exchange(const fq_state &st, fq_mail *mail, u
 		while (fq_lds_load(&mail->published) <= r) {
 			if (++idle > FQ_IDLE_LIMIT || ((idle & 1023u) == 0 && __hip_atomic_load(st.abort_flag, __ATOMIC_RELAXED,
 												  __HIP_MEMORY_SCOPE_AGENT))) {
-				if (lane == 0)
-					__hip_atomic_store(st.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				fq_lds_store(&mail->abort, 1u);
+				fq_give_up(st, mail, group, r, 1u, rows_done, lane);
 				return;
 			}
 			__builtin_amdgcn_s_sleep(2);
@@ -413,8 +436,15 @@ __device__ __forceinline__ void fq_exchange(const fq_state &st, fq_mail *mail, u
 			uint32_t before = 0;
 			ok = ok && (group == 0 || fq_row_sum(cur, group, lane, before));
 			if (ok) {
-				if (lane == 0)
-					mail->base[r % uint32_t(FQ_QDEPTH)] = base + (uint64_t(before) << 4);
+				// the workgroup's tiles of a round follow one another: every worker's
+				// offset from the sizes the workers left (all final: the round is
+				// published), so that no worker reads another's size later, when its
+				// owner may be rounds ahead
+				const uint32_t slot = r % uint32_t(FQ_QDEPTH);
+				const uint32_t mine = lane < FQ_WORKERS ? mail->bytes[slot][lane] : 0u;
+				const uint32_t upto = wave_scan<uint32_t>(mine, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+				if (lane < FQ_WORKERS)
+					mail->base[slot][lane] = base + (uint64_t(before) << 4) + (upto - mine);
 				fq_lds_store(&mail->resolved, r + 1u);
 				FQ_COUNT(1, lane);
 				idle = 0;
@@ -427,9 +457,7 @@ __device__ __forceinline__ void fq_exchange(const fq_state &st, fq_mail *mail, u
 				if (lane == 0 && group < 3)
 					printf("exchanger %u gives up in round %u of %u\n", group, r, rounds);
 #endif
-				if (lane == 0)
-					__hip_atomic_store(st.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				fq_lds_store(&mail->abort, 1u);
+				fq_give_up(st, mail, group, r, 2u, rows_done, lane);
 				return;
 			}
 			__builtin_amdgcn_s_sleep(8);
@@ -511,10 +539,7 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 	auto flush = [&]() {
 		const uint32_t slot = flushed % uint32_t(FQ_QDEPTH);
 		const size_t t = first + size_t(flushed) * per_round;
-		// the workgroup's tiles of a round follow one another
-		uint64_t base = uniform(mail.base[slot]);
-		for (int w = 0; w < wave; w++)
-			base += uniform(mail.bytes[slot][w]);
+		const uint64_t base = uniform(mail.base[slot][wave]);
 		const uint32_t pos = uniform(queue[slot][0]), total = uniform(queue[slot][1]);
 		const uint32_t s0 = uniform(queue[slot][2]), s1 = uniform(queue[slot][3]), s2 = uniform(queue[slot][4]);
 		for (uint32_t o = uint32_t(lane) * 16u; o < total; o += WAVE * 16u)
@@ -635,7 +660,13 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 					__hip_atomic_store(&st.rows[size_t(r) * FQ_MAX_GROUPS + group], uint16_t(FQ_ROW_VALID | sum16),
 							   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-				fq_lds_store(&mail.published, r + 1u);
+				// (a maximum, not a store: in the array's last round, which not
+				// every worker has, the round's last worker can get here ahead
+				// of the last worker of the round before)
+				asm volatile("" ::: "memory");
+				if (lane == 0)
+					__hip_atomic_fetch_max(&mail.published, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				asm volatile("" ::: "memory");
 			}
 		}
 		FQ_TIME(2, lane, t_mid);
