@@ -156,32 +156,28 @@ constexpr int FIELDS_MIN_NB = 4;
 constexpr int FIELDS_PAD = 128 / FIELDS_MIN_NB;
 
 // Binary decision tree over the (wave-uniform) width: five or six scalar
-// branches lead to the code specialised for it.
+// branches lead to the code specialised for it.  The walk over the packed
+// blocks (lane j takes blocks j, j + 64, ...) is inside each leaf: with the tree
+// inside the walk the compiler evaluates every comparison of the tree ahead of
+// the loop and parks the results in spilled scalar registers, some two hundred
+// instructions a call.
 template <typename C, int LO, int HI>
-__device__ __forceinline__ void unpack_dispatch(uint32_t nb, const uint32_t (&w)[4], C *slots, int j)
+__device__ __forceinline__ void unpack_blocks_dispatch(uint32_t nb, const uint8_t *packed, uint32_t nblk,
+						       int lane, C *slots)
 {
 	if constexpr (LO == HI) {
-		unpack_fields<C, LO>(w, slots, j);
+		for (uint32_t j = uint32_t(lane); j < nblk; j += 64u) {
+			const uint2 *q = reinterpret_cast<const uint2 *>(packed) + j * 2;
+			const uint2 a = q[0], b = q[1];
+			const uint32_t w[4] = {a.x, a.y, b.x, b.y};
+			unpack_fields<C, LO>(w, slots, int(j));
+		}
 	} else {
 		constexpr int MID = (LO + HI) / 2;
 		if (nb <= uint32_t(MID))
-			unpack_dispatch<C, LO, MID>(nb, w, slots, j);
+			unpack_blocks_dispatch<C, LO, MID>(nb, packed, nblk, lane, slots);
 		else
-			unpack_dispatch<C, MID + 1, HI>(nb, w, slots, j);
-	}
-}
-
-template <typename C, int LO, int HI>
-__device__ __forceinline__ void pack_dispatch(uint32_t nb, const C *slots, int j, uint32_t (&w)[4])
-{
-	if constexpr (LO == HI) {
-		pack_fields<C, LO>(slots, j, w);
-	} else {
-		constexpr int MID = (LO + HI) / 2;
-		if (nb <= uint32_t(MID))
-			pack_dispatch<C, LO, MID>(nb, slots, j, w);
-		else
-			pack_dispatch<C, MID + 1, HI>(nb, slots, j, w);
+			unpack_blocks_dispatch<C, MID + 1, HI>(nb, packed, nblk, lane, slots);
 	}
 }
 

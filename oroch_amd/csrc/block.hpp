@@ -268,12 +268,7 @@ __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv
 			// lane j unpacks packed block j with compile-time field positions
 			const uint32_t nblk = pck_space(wt, uint32_t(nv), nb) >> 4;
 			// (widths above 32 bits have more than 64 packed blocks)
-			for (uint32_t j = uint32_t(lane); j < nblk; j += WAVE) {
-				const uint2 *q = reinterpret_cast<const uint2 *>(img8 + doff) + j * 2;
-				const uint2 a = q[0], b = q[1];
-				const uint32_t w[4] = {a.x, a.y, b.x, b.y};
-				unpack_dispatch<C, FIELDS_MIN_NB, E::W>(nb, w, val, int(j));
-			}
+			unpack_blocks_dispatch<C, FIELDS_MIN_NB, E::W>(nb, img8 + doff, nblk, lane, val);
 		} else {
 			// narrow fields: one value per lane and step
 			const uint4 we = wt[nb];
