@@ -212,10 +212,13 @@ __device__ __forceinline__ uint32_t group_mask(uint64_t ballot)
 // in lanes 0..4) that qualify for the four-block path and returns them as a
 // bit mask; the caller does the others one by one.  The 256 values of block s
 // of the quad go to sink(s, lane, v), lane l holding values 4l .. 4l+3.
-template <typename E, typename Sink>
+// When all four blocks qualify, staged() is called once the quad's bytes are no
+// longer needed (the last two blocks are unpacked but not yet handed out): the
+// caller may overwrite qbuf there.
+template <typename E, typename Sink, typename Staged>
 __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint32_t qbytes, uint32_t rel,
 						  int lane, typename E::C *slots, uint8_t *ends,
-						  const uint4 *wt, Sink &&sink)
+						  const uint4 *wt, Sink &&sink, Staged &&staged)
 {
 	using C = typename E::C;
 	static_assert(sizeof(C) == 4, "element types up to 32 bits");
@@ -339,6 +342,8 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 		atomicOr(&slots[now ? __umul24(uint32_t(g & 1), SLOT_STRIDE) + pos : uint32_t(2 * SLOT_STRIDE - 1)],
 			 now ? patch : C(0));
 		wave_sync();
+		if (half == 1 && fast == 15u)
+			staged();
 		// every lane picks up four values of each block; origin and encoding
 		// of block s come from the first lane of its group
 #pragma unroll
@@ -362,10 +367,19 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 
 // Persistent wavefronts over quads of blocks; offsets are fetched two quads
 // ahead and the quad's bytes one quad ahead (the first 3 KiB of them, into
-// registers that are free again once the current quad is staged in LDS), so
-// the dependent latencies overlap with decoding.  The loop is latency-bound
-// (a chain of LDS round trips per quad): registers and LDS are kept to what
-// five wavefronts per SIMD allow.
+// registers), so the dependent latencies overlap with decoding.  The loop is
+// latency-bound (a chain of LDS round trips per quad): registers and LDS are
+// kept to what five wavefronts per SIMD allow.
+//
+// Where the loads are waited for matters.  The compiler's wait counts assume
+// the fewest younger memory operations any path can have issued, and the
+// stores of a quad sit under conditions, so a wait for a load that has stores
+// after it is a wait for everything, stores included.  The next quad's bytes
+// are therefore awaited and moved to LDS as soon as this quad's are no longer
+// needed, ahead of its last stores, and the loads for the quad after that are
+// issued there too; what is younger than those loads at their wait are stores
+// that have had most of a quad's decoding to complete.  All loads of the walk
+// are unconditional (clamped addresses) for the same reason.
 //
 // want(first block of the quad) is asked before a quad is decoded: WALK_STOP
 // ends this wavefront's walk.  The values of block blk (nv of them) go to
@@ -396,21 +410,23 @@ __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 	const size_t nquads = (nblocks + QUAD - 1) / QUAD;
 	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
 
-	// lanes 0..4 hold the offsets of the quad's blocks and its end
-	auto extent = [&](size_t q, uint64_t &o) {
-		o = 0;
-		if (q < nquads) {
-			size_t i = q * QUAD + size_t(lane < QUAD ? lane : QUAD);
-			if (i > nblocks)
-				i = nblocks;
-			o = __builtin_nontemporal_load(offsets + i);
-		}
-	};
 	// Offsets come from the caller's table and may be anything: the quad is
 	// confined to [0, offsets[nblocks]), the length of the stream, and to the
 	// caller's stream_limit, so a damaged table yields wrong values but no read
 	// outside the stream.
 	const uint64_t limit = min_u64(uniform(offsets[nblocks]), stream_limit);
+	// a stream without a single 16-byte piece: the loads below go to the table
+	// instead (it has two entries at least) and every quad has length zero
+	const uint8_t *bytes = limit >= 16 ? src : reinterpret_cast<const uint8_t *>(offsets);
+	const uint64_t last_piece = limit >= 16 ? (limit - 16) & ~uint64_t(15) : 0;
+
+	// lanes 0..4 hold the offsets of the quad's blocks and its end (the end of
+	// the stream for quads past the last)
+	auto extent = [&](size_t q, uint64_t &o) {
+		size_t i = (q < nquads ? q * QUAD : nblocks) + size_t(lane < QUAD ? lane : QUAD);
+		i = i < nblocks ? i : nblocks;
+		o = __builtin_nontemporal_load(offsets + i);
+	};
 	auto resolve = [&](uint64_t o, uint64_t &start, uint32_t &rel, uint32_t &total) {
 		start = min_u64(read_lane(o, 0), limit) & ~uint64_t(15);
 		const uint64_t room = limit - start;
@@ -419,50 +435,73 @@ __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 		rel = clamp_u64(d, QBYTES) & ~15u; // images start at multiples of 16
 		total = read_lane(rel, QUAD);
 	};
-	auto fetch = [&](uint64_t start, uint32_t total, uint4 (&im)[NPRE]) {
-#pragma unroll
-		for (int c = 0; c < NPRE; c++) {
-			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
-			im[c] = make_uint4(0, 0, 0, 0);
-			if (o < total)
-				im[c] = *reinterpret_cast<const uint4 *>(src + start + o);
-		}
+	// The bytes in flight, one 1 KiB piece per variable (named variables: as an
+	// array they end up in scratch memory once the register budget is tight).
+	// Pieces past the quad's length are loaded from its first piece instead
+	// and dropped when the quad is staged; no piece reaches past the stream.
+	static_assert(NPRE <= 3, "pieces in flight");
+	uint4 im0, im1, im2;
+	auto piece = [&](uint64_t start, uint32_t total, int c) {
+		const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+		const uint64_t at = start + (o < total ? o : 0u);
+		return *reinterpret_cast<const uint4 *>(bytes + (at < last_piece ? at : last_piece));
+	};
+	auto fetch = [&](uint64_t start, uint32_t total) {
+		im0 = piece(start, total, 0);
+		if constexpr (NPRE > 1)
+			im1 = piece(start, total, 1);
+		if constexpr (NPRE > 2)
+			im2 = piece(start, total, 2);
+	};
+	auto put = [&](uint32_t total, int c, const uint4 &x) {
+		const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+		if (o < total)
+			*reinterpret_cast<uint4 *>(qb + o) = x;
+	};
+	auto stage = [&](uint64_t start, uint32_t total) {
+		put(total, 0, im0);
+		if constexpr (NPRE > 1)
+			put(total, 1, im1);
+		if constexpr (NPRE > 2)
+			put(total, 2, im2);
+		// a quad longer than what was fetched ahead: the rest, now
+		for (uint32_t o = uint32_t(NPRE) * 1024u + uint32_t(lane) * 16u; o < total; o += 1024u)
+			*reinterpret_cast<uint4 *>(qb + o) = *reinterpret_cast<const uint4 *>(src + start + o);
 	};
 
 	size_t q = size_t(blockIdx.x) * WAVES_PER_WG + wave;
-	uint64_t o0, o1, o2, start0, start1;
+	// rel0/total0: the quad staged in LDS; start1/rel1/total1 and im: the next
+	// quad, in flight; o1: the offsets of the one after it, in flight
+	uint64_t o0, o1, start0, start1;
 	uint32_t rel0, rel1, total0, total1;
-	uint4 im[NPRE];
 	extent(q, o0);
 	extent(q + stride, o1);
 	resolve(o0, start0, rel0, total0);
-	fetch(start0, total0, im);
-	for (; q < nquads; q += stride) {
-#pragma unroll
-		for (int c = 0; c < NPRE; c++) {
-			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
-			if (o < total0)
-				*reinterpret_cast<uint4 *>(qb + o) = im[c];
-		}
-		// a quad longer than what was fetched ahead: the rest, now
-		for (uint32_t o = uint32_t(NPRE) * 1024u + uint32_t(lane) * 16u; o < total0; o += 1024u)
-			*reinterpret_cast<uint4 *>(qb + o) = *reinterpret_cast<const uint4 *>(src + start0 + o);
-		wave_sync();
-		// the next quad's bytes and the offsets of the one after it, on their way
-		extent(q + 2 * stride, o2);
+	fetch(start0, total0);
+	stage(start0, total0);
+	wave_sync();
+	resolve(o1, start1, rel1, total1);
+	fetch(start1, total1);
+	extent(q + 2 * stride, o1);
+	// moves the next quad in and sets the loads for the one after it going
+	auto advance = [&]() {
+		stage(start1, total1);
+		rel0 = rel1;
+		total0 = total1;
 		resolve(o1, start1, rel1, total1);
-		fetch(start1, total1, im);
-
+		fetch(start1, total1);
+		extent(q + 3 * stride, o1);
+	};
+	for (; q < nquads; q += stride) {
 		const size_t blk0 = q * QUAD;
 		const size_t base = blk0 * BLOCK;
 		if (want(blk0) == WALK_STOP)
 			break;
 		uint32_t done = 0;
 		if (blk0 + QUAD <= nblocks && base + size_t(QUAD) * BLOCK <= n)
-			done = decode_quad_fast<E>(qbuf, total0, rel0, lane, slots, endss[wave], wt,
-						   [&](int s, int ln, const C(&v)[VPL]) {
-							   sink(blk0 + size_t(s), BLOCK, ln, v);
-						   });
+			done = decode_quad_fast<E>(
+				qbuf, total0, rel0, lane, slots, endss[wave], wt,
+				[&](int s, int ln, const C(&v)[VPL]) { sink(blk0 + size_t(s), BLOCK, ln, v); }, advance);
 		if (done != 15u) {
 			// the others one by one, from the same staged bytes
 			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
@@ -482,13 +521,9 @@ __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 				sink(blk0 + size_t(b), nv, lane, v);
 				wave_sync();
 			}
+			advance();
 		}
 		wave_sync();
-
-		o1 = o2;
-		start0 = start1;
-		rel0 = rel1;
-		total0 = total1;
 	}
 }
 

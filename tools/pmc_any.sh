@@ -1,11 +1,11 @@
 #!/bin/bash
 # instruction counters of the group kernels on any input of tools/time_any.py:
-#   DT=int64 KIND=mix LOG2N=26 tools/pmc_any.sh <out name>
+#   DT=int64 KIND=mix LOG2N=26 [PMC="counter ..."] tools/pmc_any.sh <out name>
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export LOG2N=${LOG2N:-26}
-timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $R/gpurun_out/$1 -o pmc --output-format csv -- python3 $R/tools/time_any.py > $R/gpurun_out/$1.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc ${PMC:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY} -d $R/gpurun_out/$1 -o pmc --output-format csv -- python3 $R/tools/time_any.py > $R/gpurun_out/$1.log 2>&1
 python3 - $R/gpurun_out/$1 <<'PY'
 import csv, collections, sys, glob, os
 f = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)[0]
