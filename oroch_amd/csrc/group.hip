@@ -21,6 +21,30 @@
 #include "scan.hpp"
 #include "block.hpp"
 
+// Most workgroups a launch of each block kernel asks for; beyond that a
+// workgroup takes several tiles in turn.  Found by measurement: the decoder
+// of four blocks per wavefront keeps offsets and stream bytes of the tiles
+// ahead in flight and wants long-lived workgroups, the others run faster when
+// the dispatcher replaces short-lived workgroups more often.
+#ifndef GRID_SELECT_QUAD
+#define GRID_SELECT_QUAD 16384u
+#endif
+#ifndef GRID_ENCODE_QUAD
+#define GRID_ENCODE_QUAD 65536u
+#endif
+#ifndef GRID_DECODE_QUAD
+#define GRID_DECODE_QUAD 16384u
+#endif
+#ifndef GRID_SELECT
+#define GRID_SELECT 65536u
+#endif
+#ifndef GRID_ENCODE
+#define GRID_ENCODE 65536u
+#endif
+#ifndef GRID_DECODE
+#define GRID_DECODE 262144u
+#endif
+
 namespace oroch_hip {
 
 // Wave-uniform outcome of selection for one block.
@@ -1209,14 +1233,14 @@ static int launch_select(const void *src, size_t n, size_t nb, oroch_block_desc 
 		if (!option(OROCH_OPT_SELECT_ONE_BLOCK)) {
 			const size_t nq = (nb + QUAD - 1) / QUAD;
 			unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
-			qgrid = qgrid < 16384u ? qgrid : 16384u;
+			qgrid = qgrid < GRID_SELECT_QUAD ? qgrid : GRID_SELECT_QUAD;
 			hipLaunchKernelGGL(k_select_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 					   static_cast<const typename E::S *>(src), n, nb, desc, sizes);
 			return int(hipGetLastError());
 		}
 	}
 	const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
-	hipLaunchKernelGGL(k_select<E>, dim3(grid < 16384u ? grid : 16384u), dim3(WAVE * WAVES_PER_WG), 0, st,
+	hipLaunchKernelGGL(k_select<E>, dim3(grid < GRID_SELECT ? grid : GRID_SELECT), dim3(WAVE * WAVES_PER_WG), 0, st,
 			   static_cast<const typename E::S *>(src), n, nb, desc, sizes);
 	return int(hipGetLastError());
 }
@@ -1280,7 +1304,7 @@ extern "C" int oroch_group_stats(int dtype, const void *src, size_t n, oroch_blo
 		using E = decltype(e);
 		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
 		profile_scope ps(OROCH_K_SELECT, st);
-		hipLaunchKernelGGL(k_stats<E>, dim3(grid < 16384u ? grid : 16384u), dim3(WAVE * WAVES_PER_WG),
+		hipLaunchKernelGGL(k_stats<E>, dim3(grid < GRID_SELECT ? grid : GRID_SELECT), dim3(WAVE * WAVES_PER_WG),
 				   0, st, static_cast<const typename E::S *>(src), n, nb, stats);
 		return int(hipGetLastError());
 	});
@@ -1335,14 +1359,14 @@ static int group_encode_impl(int dtype, const void *src, size_t n, void *dst, si
 				if (!one_block_encode_forced()) {
 					const size_t nq = (nb + QUAD - 1) / QUAD;
 					unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
-					qgrid = qgrid < 16384u ? qgrid : 16384u;
+					qgrid = qgrid < GRID_ENCODE_QUAD ? qgrid : GRID_ENCODE_QUAD;
 					hipLaunchKernelGGL(k_encode_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 							   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
 							   static_cast<uint8_t *>(dst));
 					return int(hipGetLastError());
 				}
 			}
-			hipLaunchKernelGGL(k_encode<E>, dim3(grid < 16384u ? grid : 16384u),
+			hipLaunchKernelGGL(k_encode<E>, dim3(grid < GRID_ENCODE ? grid : GRID_ENCODE),
 					   dim3(WAVE * WAVES_PER_WG), 0, st,
 					   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
 					   static_cast<uint8_t *>(dst));
@@ -1547,14 +1571,14 @@ int oroch_hip::group_decode_within(int dtype, const void *src, const uint64_t *o
 		unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
 		// more workgroups than the chip holds at once: the dispatcher then
 		// evens out blocks of different cost
-		grid = grid < 16384u ? grid : 16384u;
+		grid = grid < GRID_DECODE ? grid : GRID_DECODE;
 		profile_scope ps(OROCH_K_DECODE, st);
 		if constexpr (sizeof(typename E::C) == 4) {
 			if (!one_block_decode_forced()) {
 				// four blocks per wavefront
 				const size_t nq = (nb + QUAD - 1) / QUAD;
 				unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
-				qgrid = qgrid < 16384u ? qgrid : 16384u;
+				qgrid = qgrid < GRID_DECODE_QUAD ? qgrid : GRID_DECODE_QUAD;
 				hipLaunchKernelGGL(k_decode_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 						   static_cast<const uint8_t *>(src), offsets, n, nb, stream_bytes,
 						   static_cast<typename E::S *>(dst));

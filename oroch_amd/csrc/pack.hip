@@ -14,6 +14,9 @@
 
 namespace oroch_hip {
 
+#ifndef PACK_GRID_CAP
+#define PACK_GRID_CAP 32768
+#endif
 constexpr int PK_THREADS = 256;
 constexpr int PK_TILE_VALUES = 4096;   // values staged per tile (upper bound)
 constexpr int PK_MAX_BLOCKS = 1024;    // 16-byte blocks per tile (upper bound)
@@ -104,28 +107,60 @@ __device__ __forceinline__ void join16(const typename E::C (&v)[16 / E::BYTES], 
 	*to = make_uint4(d[0], d[1], d[2], d[3]);
 }
 
-// FLAGS: also writes the map of exceptions (bitpfr.h:75-85), bit v of the map
-// set when value v does not fit nbits once the origin is taken off.
-template <typename E, int VC, bool FLAGS = false>
+// What the packer leaves behind for the exception lists of a patched sequence
+// (bitpfr.h:75-85): per tile of the packer the number of exceptions and the
+// position of the last one, and, for tiles with at most `room` of them, the
+// exceptions themselves in order of arrival (position inside the tile, high
+// part).
+constexpr uint64_t XT_NONE = ~uint64_t(0);
+struct exc_notes
+{
+	uint32_t *counts; // per tile
+	uint64_t *last;   // per tile: position in the sequence, XT_NONE when the tile has none
+	uint16_t *spos;   // room entries per tile
+	uint64_t *sval;
+	uint32_t room;
+};
+
+// Entries per tile of tile_values values: one for every 32 values.  Tiles with
+// more exceptions than that are read again by the list pass.
+static inline uint32_t exc_room(uint32_t tile_values)
+{
+	return tile_values / 32;
+}
+
+// EXC: also notes the exceptions (exc_notes), value v of the sequence being one
+// when it does not fit nbits once the origin is taken off.  The high parts are
+// at hand here, so the list pass need not look the values up again: a thread
+// that has met exceptions in a tile takes places for them in a list in LDS
+// (one counter), and once the tile is packed the list goes to the tile's notes
+// as it is; the list pass puts the entries in order.  Two lists take turns, so
+// that a tile's list can go out while the next tile's values come in.
+template <typename E, int VC, bool EXC = false>
 __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, size_t n,
 						       size_t nblk, pack_geom g, typename E::C origin,
-						       uint64_t *dst, uint64_t *map = nullptr)
+						       uint64_t *dst, exc_notes xn = exc_notes())
 {
 	using C = typename E::C;
 	using S = typename E::S;
 	constexpr int PK_VEC = 16 / E::BYTES; // values per 16-byte load
+	constexpr int ROOM = PK_TILE_VALUES / 32; // exc_room of the largest tile
 	__shared__ __attribute__((aligned(16))) S stage[PK_TILE_VALUES];
-	__shared__ uint32_t bits[FLAGS ? PK_TILE_VALUES / 32 : 1];
+	// exceptions met in a tile; position of the highest, plus one; the list
+	__shared__ uint32_t found[2], top[2];
+	__shared__ uint16_t upos[EXC ? 2 : 1][EXC ? ROOM : 1];
+	__shared__ C uval[EXC ? 2 : 1][EXC ? ROOM : 1];
 	const C low = g.nbits >= uint32_t(E::W) ? E::MASK : C((C(1) << (g.nbits % E::W)) - 1);
 	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
 	// (tiles start at multiples of 64 values: 16-byte loads are aligned when src is)
 	const bool wide_ok = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (g.tile_blocks * g.cap) % 64 == 0;
-	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		if constexpr (FLAGS) {
-			if (threadIdx.x < PK_TILE_VALUES / 32)
-				bits[threadIdx.x] = 0;
-			__syncthreads();
-		}
+	int turn = 0;
+	if constexpr (EXC) {
+		if (threadIdx.x < 2)
+			found[threadIdx.x] = top[threadIdx.x] = 0;
+		__syncthreads();
+	}
+	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, turn ^= 1) {
 		const size_t b0 = tile * g.tile_blocks;
 		const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
 		const size_t v0 = b0 * g.cap;
@@ -138,11 +173,13 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, s
 			const uint4 *from = reinterpret_cast<const uint4 *>(src + v0);
 			const uint32_t nvec = slots / PK_VEC;
 			uint4 x[ROUNDS];
+			uint32_t nibs[ROUNDS];
 #pragma unroll
 			for (int r = 0; r < ROUNDS; r++) {
 				const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
 				x[r] = j < nvec ? from[j] : make_uint4(0, 0, 0, 0);
 			}
+			uint32_t mine = 0;
 #pragma unroll
 			for (int r = 0; r < ROUNDS; r++) {
 				const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
@@ -153,32 +190,61 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, s
 				for (int k = 0; k < PK_VEC; k++) {
 					const C u = value_encode<E, VC>(raw[k], origin);
 					raw[k] = u & low;
-					if constexpr (FLAGS)
+					if constexpr (EXC)
 						nib |= ((u >> g.nbits) != 0 ? 1u : 0u) << k;
 				}
-				if (j < nvec) {
+				nibs[r] = j < nvec ? nib : 0u;
+				mine += uint32_t(__popc(nibs[r]));
+				if (j < nvec)
 					join16<E>(raw, reinterpret_cast<uint4 *>(stage) + j);
-					if constexpr (FLAGS) {
-						if (nib)
-							atomicOr(&bits[(j * PK_VEC) / 32], nib << ((j * PK_VEC) % 32));
+			}
+			if constexpr (EXC) {
+				if (mine) {
+					uint32_t slot = atomicAdd(&found[turn], mine);
+					uint32_t hp = 0;
+#pragma unroll
+					for (int r = 0; r < ROUNDS; r++) {
+						if (nibs[r]) {
+							const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
+							hp = j * PK_VEC + 32u - uint32_t(__clz(nibs[r]));
+							C raw[PK_VEC];
+							split16<E>(x[r], raw);
+#pragma unroll
+							for (int k = 0; k < PK_VEC; k++) {
+								if ((nibs[r] >> k) & 1u) {
+									if (slot < xn.room) {
+										upos[turn][slot] = uint16_t(j * PK_VEC + uint32_t(k));
+										uval[turn][slot] = C(value_encode<E, VC>(raw[k], origin) >> g.nbits);
+									}
+									slot++;
+								}
+							}
+						}
 					}
+					atomicMax(&top[turn], hp);
 				}
 			}
 		} else {
 			for (uint32_t i = threadIdx.x; i < slots; i += PK_THREADS) {
 				const C u = i < nvals ? value_encode<E, VC>(C(src[v0 + i]), origin) : C(0);
 				stage[i] = S(u & low);
-				if constexpr (FLAGS) {
-					if ((u >> g.nbits) != 0)
-						atomicOr(&bits[i / 32], 1u << (i % 32));
+				if constexpr (EXC) {
+					if ((u >> g.nbits) != 0) {
+						const uint32_t slot = atomicAdd(&found[turn], 1u);
+						atomicMax(&top[turn], i + 1u);
+						if (slot < xn.room) {
+							upos[turn][slot] = uint16_t(i);
+							uval[turn][slot] = C(u >> g.nbits);
+						}
+					}
 				}
 			}
 		}
 		__syncthreads();
-		if constexpr (FLAGS) {
-			// the tile's words of the map (v0 and the tile length are multiples of 64)
-			if (threadIdx.x < (slots + 63) / 64)
-				map[v0 / 64 + threadIdx.x] = (uint64_t(bits[2 * threadIdx.x + 1]) << 32) | bits[2 * threadIdx.x];
+		if constexpr (EXC) {
+			// (everybody is done with the other list: it is empty again for the next tile)
+			if (threadIdx.x == 0)
+				found[turn ^ 1] = top[turn ^ 1] = 0;
 		}
 		for (uint32_t q = threadIdx.x; q < 2 * tb; q += PK_THREADS) {
 			const uint32_t blk = q >> 1, w = q & 1;
@@ -192,6 +258,18 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, s
 			dst[b0 * 2 + q] = acc;
 		}
 		__syncthreads();
+		if constexpr (EXC) {
+			const uint32_t count = found[turn];
+			if (threadIdx.x == 0) {
+				xn.counts[tile] = count;
+				xn.last[tile] = top[turn] ? v0 + top[turn] - 1 : XT_NONE;
+			}
+			if (count <= xn.room && threadIdx.x < count) {
+				const size_t at = tile * xn.room + threadIdx.x;
+				xn.spos[at] = upos[turn][threadIdx.x];
+				xn.sval[at] = uint64_t(uval[turn][threadIdx.x]);
+			}
+		}
 	}
 }
 
@@ -447,115 +525,121 @@ __global__ __launch_bounds__(PK_THREADS) void k_fetch(const uint64_t *src, size_
 
 // ---- bitpfr exception lists ---------------------------------------------------------
 //
-// A tile is 16384 consecutive values handled by one 256-thread workgroup, one
-// 64-bit word of the exception map per thread.
+// The packer has noted per tile how many exceptions it holds, where the last
+// one sits and (unless they are too many) the exceptions themselves, in no
+// particular order; a scan of the counts gives every tile the rank of its
+// first exception.  One wavefront
+// per tile then writes the tile's part of the two lists: gap-coded positions
+// (offset.h:55-60 with offset 1) and high parts (bitpfr.h:75-85).
 
-constexpr int XT_THREADS = 256;
-constexpr int XT_VPT = 64;
-constexpr int XT_TILE = XT_THREADS * XT_VPT;
-constexpr uint64_t XT_NONE = ~uint64_t(0);
+constexpr int XL_THREADS = 256;
+constexpr int XL_MAP = PK_TILE_VALUES / 32;   // words of a map with one bit per value of a tile
+constexpr int XL_ROOM = PK_TILE_VALUES / 32;  // exc_room of the largest tile
 
-// The word of the exception map for values base .. base + 63 (base a multiple
-// of 64).
-__device__ __forceinline__ uint64_t exc_flags(const uint64_t *map, size_t base)
-{
-	return map[base / 64];
-}
-
-// Pass 1: per tile of XT_TILE values, the number of exceptions and the position
-// of the last one.
-__global__ __launch_bounds__(XT_THREADS) void k_exc_count(const uint64_t *map, uint32_t *counts,
-							    uint64_t *last)
-{
-	__shared__ uint32_t wave_cnt[XT_THREADS / WAVE], wave_last[XT_THREADS / WAVE];
-	const size_t tile_base = size_t(blockIdx.x) * XT_TILE;
-	const uint64_t flags = exc_flags(map, tile_base + size_t(threadIdx.x) * XT_VPT);
-	const uint32_t cnt = wave_sum(uint32_t(__popcll(flags)));
-	// highest position in the tile with an exception, plus one; 0 = none
-	const uint32_t lp = wave_max(flags ? threadIdx.x * XT_VPT + (63u - uint32_t(__clzll(flags))) + 1u : 0u);
-	if (lane_id() == 0) {
-		wave_cnt[threadIdx.x / WAVE] = cnt;
-		wave_last[threadIdx.x / WAVE] = lp;
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t total = 0, m = 0;
-		for (int w = 0; w < XT_THREADS / WAVE; w++) {
-			total += wave_cnt[w];
-			m = wave_last[w] > m ? wave_last[w] : m;
-		}
-		counts[blockIdx.x] = total;
-		last[blockIdx.x] = m ? tile_base + m - 1 : XT_NONE;
-	}
-}
-
-// Pass 2: emit (gap, high part) per exception at its global rank.
 template <typename E>
-__global__ __launch_bounds__(XT_THREADS) void k_exc_emit(const typename E::S *src, const uint64_t *map,
-							   typename E::C origin, uint32_t nbits,
-							   const uint32_t *counts, const uint64_t *last,
-							   const uint64_t *rank_base, uint64_t *indices,
-							   uint64_t *values, size_t capacity)
+__global__ __launch_bounds__(XL_THREADS) void k_exc_lists(const typename E::S *src, size_t n,
+							    typename E::C origin, uint32_t nbits,
+							    uint32_t tile_values, size_t ntiles, exc_notes xn,
+							    const uint64_t *rank_base, uint64_t *indices,
+							    uint64_t *values, size_t capacity, uint64_t *nexc)
 {
 	using C = typename E::C;
-	__shared__ uint64_t before_tile;
-	__shared__ uint32_t wave_cnt[XT_THREADS / WAVE], wave_last[XT_THREADS / WAVE];
-	const size_t tile = blockIdx.x;
-	if (counts[tile] == 0)
+	__shared__ uint32_t maps[XL_THREADS / WAVE][XL_MAP], unders[XL_THREADS / WAVE][XL_MAP];
+	__shared__ uint16_t sorteds[XL_THREADS / WAVE][XL_ROOM];
+	const int lane = lane_id();
+	const size_t tile = size_t(blockIdx.x) * (XL_THREADS / WAVE) + threadIdx.x / WAVE;
+	if (tile >= ntiles)
 		return;
-	const int lane = lane_id(), wave = threadIdx.x / WAVE;
+	if (tile + 1 == ntiles && lane == 0)
+		*nexc = rank_base[ntiles];
+	const uint32_t count = uniform(xn.counts[tile]);
+	if (count == 0)
+		return;
 	// The last exception before this tile: the nearest earlier tile that has
-	// one, looked for by the first wavefront, 64 tiles per step.
-	if (wave == 0) {
-		uint64_t found = XT_NONE;
-		for (size_t hi = tile; hi > 0 && found == XT_NONE;) {
-			const size_t lo = hi > WAVE ? hi - WAVE : 0;
-			const size_t t = lo + size_t(lane);
-			const uint64_t x = t < hi ? last[t] : XT_NONE;
-			const uint64_t have = __ballot(x != XT_NONE);
-			if (have)
-				found = read_lane(x, 63 - __builtin_clzll(have));
-			hi = lo;
+	// one, 64 tiles per step.
+	uint64_t before = XT_NONE;
+	for (size_t hi = tile; hi > 0 && before == XT_NONE;) {
+		const size_t lo = hi > WAVE ? hi - WAVE : 0;
+		const size_t t = lo + size_t(lane);
+		const uint64_t x = t < hi ? xn.last[t] : XT_NONE;
+		const uint64_t have = __ballot(x != XT_NONE);
+		if (have)
+			before = read_lane(x, 63 - __builtin_clzll(have));
+		hi = lo;
+	}
+	const uint64_t v0 = uint64_t(tile) * tile_values;
+	const uint64_t rank0 = rank_base[tile];
+	// the position a gap counts from: one past the exception before, 0 at the start
+	const uint64_t next0 = before == XT_NONE ? 0 : before + 1;
+	if (count <= xn.room) {
+		// The packer's notes, in the order its threads met the exceptions: a map
+		// of the positions gives every entry its rank in the tile.
+		static_assert(XL_ROOM == 2 * WAVE && XL_MAP == 2 * WAVE, "two entries and two words of the map per lane");
+		uint32_t *map = maps[threadIdx.x / WAVE], *under = unders[threadIdx.x / WAVE];
+		uint16_t *sorted = sorteds[threadIdx.x / WAVE];
+		const uint16_t *spos = xn.spos + tile * xn.room;
+		const uint64_t *sval = xn.sval + tile * xn.room;
+		map[2 * lane] = map[2 * lane + 1] = 0;
+		wave_sync();
+		uint32_t p[2] = {0, 0}, r[2];
+		uint64_t hv[2] = {0, 0};
+#pragma unroll
+		for (int t = 0; t < 2; t++) {
+			const uint32_t e = uint32_t(lane) + uint32_t(t) * WAVE;
+			if (e < count) {
+				p[t] = spos[e];
+				hv[t] = sval[e];
+				atomicOr(&map[p[t] / 32], 1u << (p[t] % 32));
+			}
 		}
-		if (lane == 0)
-			before_tile = found;
-	}
-
-	const size_t tile_base = tile * XT_TILE;
-	const size_t base = tile_base + size_t(threadIdx.x) * XT_VPT;
-	uint64_t flags = exc_flags(map, base);
-	const uint32_t cnt = uint32_t(__popcll(flags));
-	const uint32_t incl_cnt = wave_scan_sum(cnt, lane);
-	// last exception at or below this thread, as tile position + 1 (0 = none)
-	const int lp = flags ? int(threadIdx.x * XT_VPT + (63u - uint32_t(__clzll(flags))) + 1u) : 0;
-	const int incl_last = wave_scan_max(lp, lane);
-	if (lane == WAVE - 1) {
-		wave_cnt[wave] = incl_cnt;
-		wave_last[wave] = uint32_t(incl_last);
-	}
-	__syncthreads();
-	uint32_t rank_in_tile = incl_cnt - cnt;
-	int prevp = __shfl_up(incl_last, 1, WAVE);
-	if (lane == 0)
-		prevp = 0;
-	for (int w = 0; w < wave; w++) {
-		rank_in_tile += wave_cnt[w];
-		prevp = int(wave_last[w]) > prevp ? int(wave_last[w]) : prevp;
-	}
-	uint64_t rank = rank_base[tile] + rank_in_tile;
-	const uint64_t before = before_tile;
-	// next expected position (offset.h:55-60): previous + 1, or 0 at the start
-	uint64_t next = prevp ? tile_base + uint64_t(prevp) : (before == XT_NONE ? 0 : before + 1);
-	while (flags) {
-		const uint64_t pos = base + uint64_t(__builtin_ctzll(flags));
-		flags &= flags - 1u;
-		if (rank < capacity) {
-			const C u = C((C(src[pos]) - origin) & E::MASK);
-			indices[rank] = pos - next;
-			values[rank] = uint64_t(u >> nbits);
+		wave_sync();
+		{
+			const uint32_t w0 = map[2 * lane], w1 = map[2 * lane + 1];
+			const uint32_t c0 = uint32_t(__popc(w0)), c = c0 + uint32_t(__popc(w1));
+			const uint32_t incl = wave_scan_sum(c, lane);
+			under[2 * lane] = incl - c;
+			under[2 * lane + 1] = incl - c + c0;
 		}
-		next = pos + 1;
-		rank++;
+		wave_sync();
+#pragma unroll
+		for (int t = 0; t < 2; t++) {
+			const uint32_t e = uint32_t(lane) + uint32_t(t) * WAVE;
+			if (e < count) {
+				r[t] = under[p[t] / 32] + uint32_t(__popc(map[p[t] / 32] & ((1u << (p[t] % 32)) - 1u)));
+				sorted[r[t]] = uint16_t(p[t]);
+			}
+		}
+		wave_sync();
+#pragma unroll
+		for (int t = 0; t < 2; t++) {
+			const uint32_t e = uint32_t(lane) + uint32_t(t) * WAVE;
+			if (e < count && rank0 + r[t] < capacity) {
+				const uint64_t from = r[t] ? v0 + sorted[r[t] - 1] + 1 : next0;
+				indices[rank0 + r[t]] = v0 + p[t] - from;
+				values[rank0 + r[t]] = hv[t];
+			}
+		}
+		return;
+	}
+	// a tile with many exceptions: its values once more, 64 at a time
+	const uint64_t end = v0 + tile_values < n ? v0 + tile_values : n;
+	uint64_t rank = rank0, next = next0;
+	for (uint64_t base = v0; base < end; base += WAVE) {
+		const uint64_t pos = base + uint64_t(lane);
+		const C u = pos < end ? C((C(src[pos]) - origin) & E::MASK) : C(0);
+		const bool mine = (u >> nbits) != 0;
+		const uint64_t all = __ballot(mine);
+		if (all == 0)
+			continue;
+		const uint64_t lower = all & ((uint64_t(1) << lane) - 1u);
+		const uint64_t r = rank + uint64_t(__popcll(lower));
+		const uint64_t from = lower ? base + uint64_t(63 - __builtin_clzll(lower)) + 1 : next;
+		if (mine && r < capacity) {
+			indices[r] = pos - from;
+			values[r] = uint64_t(u >> nbits);
+		}
+		rank += uint64_t(__popcll(all));
+		next = base + uint64_t(63 - __builtin_clzll(all)) + 1;
 	}
 }
 
@@ -594,11 +678,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_patch(const uint64_t *indices,
 	}
 }
 
-__global__ void k_store_u64(uint64_t *dst, const uint64_t *src)
-{
-	*dst = *src;
-}
-
 // Dynamic LDS of k_unpack: the packed words of a tile (+16 bytes that a field
 // read may touch), with patches one slot of the compute type per value.
 static size_t unpack_lds_bytes(const pack_geom &g, int dtype, bool patch)
@@ -610,7 +689,7 @@ static size_t unpack_lds_bytes(const pack_geom &g, int dtype, bool patch)
 
 static unsigned pack_grid(size_t ntiles)
 {
-	const size_t cap = 256 * 8;
+	const size_t cap = PACK_GRID_CAP;
 	return unsigned(ntiles < cap ? (ntiles ? ntiles : 1) : cap);
 }
 
@@ -670,15 +749,19 @@ static int do_unpack(int dtype, const void *src, size_t n, uint64_t origin, unsi
 	});
 }
 
+// The packer's tiles hold between 2048 and 4096 values whatever the width
+// (make_geom with whole words).
+constexpr size_t PK_TILE_MIN = 2048;
+
 struct pfr_ws
 {
-	uint32_t *counts;
+	uint32_t *counts;     // per tile of the packer
 	uint64_t *last;
-	uint64_t *rank_base;  // ntiles + 1
+	uint64_t *rank_base;  // tiles + 1
 	uint64_t *tile_sums;
 	uint64_t *total;
-	uint64_t *map;        // one bit per value, whole tiles of XT_TILE
-	size_t map_bytes;
+	uint16_t *spos;       // the packer's notes, exc_room entries per tile
+	uint64_t *sval;
 	uint64_t *plan_first; // per tile of the unpacker (patch_plan)
 	uint64_t *plan_where;
 	size_t bytes;
@@ -691,7 +774,7 @@ static size_t up256(size_t x)
 
 static pfr_ws carve_pfr(void *ws, size_t n)
 {
-	const size_t ntiles = (n + XT_TILE - 1) / XT_TILE;
+	const size_t ntiles = n / PK_TILE_MIN + 2;
 	// the decoder scans up to n exceptions in tiles of SCAN_TILE
 	const size_t stiles = scan_tiles(n > ntiles ? n : ntiles) + 1;
 	pfr_ws w;
@@ -707,11 +790,13 @@ static pfr_ws carve_pfr(void *ws, size_t n)
 	off = up256(off + (stiles + 1) * sizeof(uint64_t));
 	w.total = reinterpret_cast<uint64_t *>(p + off);
 	off = up256(off + 256);
-	w.map = reinterpret_cast<uint64_t *>(p + off);
-	// the packer writes whole words up to the end of the last packed block
-	// (at most 127 values beyond n), the passes read whole tiles
-	w.map_bytes = (ntiles + 1) * (XT_TILE / 8);
-	off = up256(off + w.map_bytes);
+	// one entry for every 32 values of a tile (exc_room), tiles of at most 4096
+	// values: n / 32 entries and those of one tile more
+	const size_t entries = n / 32 + 2 * exc_room(PK_TILE_VALUES);
+	w.sval = reinterpret_cast<uint64_t *>(p + off);
+	off = up256(off + entries * sizeof(uint64_t));
+	w.spos = reinterpret_cast<uint16_t *>(p + off);
+	off = up256(off + entries * sizeof(uint16_t));
 	// the unpacker's tiles hold 1024 values at least
 	const size_t utiles = n / 1024 + 3;
 	w.plan_first = reinterpret_cast<uint64_t *>(p + off);
@@ -822,15 +907,15 @@ extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_
 	if (!src || !dst || (reinterpret_cast<uintptr_t>(dst) & 7u))
 		return OROCH_E_ARGUMENT;
 	pfr_ws w = carve_pfr(workspace, n);
-	const size_t ntiles = (n + XT_TILE - 1) / XT_TILE;
-	// One pass over the values packs them and maps the exceptions; the list
-	// passes then work from the map and read only the exceptions themselves.
-	int rc = int(hipMemsetAsync(w.map, 0, w.map_bytes, st));
-	if (rc)
-		return rc;
+	// One pass over the values packs them and notes the exceptions tile by
+	// tile; a scan of the tiles' counts places them in the lists.
 	const pack_geom g = make_geom(nbits, true);
 	const size_t nblk = (n + g.cap - 1) / g.cap;
 	const size_t ptiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
+	const uint32_t tile_values = g.tile_blocks * g.cap;
+	if (tile_values < PK_TILE_MIN || tile_values > uint32_t(PK_TILE_VALUES) || tile_values % 64)
+		return OROCH_E_ARGUMENT;
+	const exc_notes xn = {w.counts, w.last, w.spos, w.sval, exc_room(tile_values)};
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		using C = typename E::C;
@@ -839,17 +924,16 @@ extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_
 		{
 			profile_scope ps(OROCH_K_PACK, st);
 			hipLaunchKernelGGL((k_pack<E, VC_ORIGIN, true>), dim3(pack_grid(ptiles)), dim3(PK_THREADS), 0,
-					   st, s, n, nblk, g, org, static_cast<uint64_t *>(dst), w.map);
+					   st, s, n, nblk, g, org, static_cast<uint64_t *>(dst), xn);
 		}
 		profile_scope ps(OROCH_K_EXCEPT, st);
-		hipLaunchKernelGGL(k_exc_count, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, w.map, w.counts,
-				   w.last);
-		int r = launch_scan<uint32_t, 0>(w.counts, ntiles, w.tile_sums, w.total, w.rank_base, st);
+		int r = launch_scan<uint32_t, 0>(w.counts, ptiles, w.tile_sums, w.total, w.rank_base, st);
 		if (r)
 			return r;
-		hipLaunchKernelGGL(k_exc_emit<E>, dim3(unsigned(ntiles)), dim3(XT_THREADS), 0, st, s, w.map, org,
-				   nbits, w.counts, w.last, w.rank_base, indices, values, exc_capacity);
-		hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, st, nexc, w.rank_base + ntiles);
+		constexpr int PER = XL_THREADS / WAVE;
+		hipLaunchKernelGGL(k_exc_lists<E>, dim3(unsigned((ptiles + PER - 1) / PER)), dim3(XL_THREADS), 0, st, s,
+				   n, org, nbits, tile_values, ptiles, xn, w.rank_base, indices, values, exc_capacity,
+				   nexc);
 		return int(hipGetLastError());
 	});
 }

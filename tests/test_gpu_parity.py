@@ -202,6 +202,39 @@ def test_sparse_exceptions_far_apart(hip, oracle):
     assert np.array_equal(host(hip.bitpfr_decode(got, n, 0, 3, idx, val, np.uint32)), a)
 
 
+@pytest.mark.parametrize("dt", [np.uint8, np.int16, np.uint32, np.int64])
+def test_bitpfr_lists_mixed_density(hip, oracle, dt):
+    # stretches with few exceptions, with exactly as many as a tile of the packer keeps
+    # notes for, with more than that and with none at all, in one sequence; the source
+    # also at an address that is no multiple of 16; a list capacity below the count
+    dt = np.dtype(dt)
+    W = dt.itemsize * 8
+    rng = np.random.default_rng(21)
+    n = 70_001
+    nbits = 3
+    a = rng.integers(0, 8, n).astype(dt)
+    out = np.zeros(n, bool)
+    out[:8192] = rng.random(8192) < 0.01          # sparse
+    out[8192:16384:32] = True                      # one in 32: exactly the room of a tile
+    out[16384:24576:3] = True                      # dense
+    out[40_000:] = rng.random(n - 40_000) < 0.04   # around the limit, tile by tile
+    a[out] |= dt.type(1 << (W - 2))
+    eo, ei, ev = oracle.bitpfr_encode(a, 0, nbits)
+    for shift in (0, 1):
+        buf = dev(np.concatenate([np.zeros(shift, dt), a]))
+        x = buf[shift:]
+        got, idx, val, nexc = hip.bitpfr_encode(x, 0, nbits)
+        assert nexc == ei.size
+        assert np.array_equal(host(got), eo)
+        assert np.array_equal(host(idx).astype(np.uint64), ei)
+        assert np.array_equal(host(val).astype(np.uint64), ev)
+        assert np.array_equal(host(hip.bitpfr_decode(got, n, 0, nbits, idx, val, dt)), a)
+    got, idx, val, nexc = hip.bitpfr_encode(dev(a), 0, nbits, capacity=1000)
+    assert nexc == ei.size
+    assert np.array_equal(host(idx).astype(np.uint64)[:1000], ei[:1000])
+    assert np.array_equal(host(val).astype(np.uint64)[:1000], ev[:1000])
+
+
 def test_headline_distribution_round_trip(hip, oracle):
     # the bench workload at a size the oracle still checks byte for byte
     n = 256 * 4096
