@@ -14,9 +14,6 @@
 
 namespace oroch_hip {
 
-#ifndef PACK_GRID_CAP
-#define PACK_GRID_CAP 32768
-#endif
 constexpr int PK_THREADS = 256;
 constexpr int PK_TILE_VALUES = 4096;   // values staged per tile (upper bound)
 constexpr int PK_MAX_BLOCKS = 1024;    // 16-byte blocks per tile (upper bound)
@@ -129,13 +126,12 @@ static inline uint32_t exc_room(uint32_t tile_values)
 	return tile_values / 32;
 }
 
-// EXC: also notes the exceptions (exc_notes), value v of the sequence being one
-// when it does not fit nbits once the origin is taken off.  The high parts are
-// at hand here, so the list pass need not look the values up again: a thread
-// that has met exceptions in a tile takes places for them in a list in LDS
-// (one counter), and once the tile is packed the list goes to the tile's notes
-// as it is; the list pass puts the entries in order.  Two lists take turns, so
-// that a tile's list can go out while the next tile's values come in.
+// One tile per workgroup.  EXC: also notes the exceptions (exc_notes), value v
+// of the sequence being one when it does not fit nbits once the origin is taken
+// off.  The high parts are at hand here, so the list pass need not look the
+// values up again: a thread that has met exceptions takes places for them in a
+// list in LDS (one counter), and once the tile is packed the list goes to the
+// tile's notes as it is; the list pass puts the entries in order.
 template <typename E, int VC, bool EXC = false>
 __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, size_t n,
 						       size_t nblk, pack_geom g, typename E::C origin,
@@ -146,129 +142,127 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack(const typename E::S *src, s
 	constexpr int PK_VEC = 16 / E::BYTES; // values per 16-byte load
 	constexpr int ROOM = PK_TILE_VALUES / 32; // exc_room of the largest tile
 	__shared__ __attribute__((aligned(16))) S stage[PK_TILE_VALUES];
-	// exceptions met in a tile; position of the highest, plus one; the list
-	__shared__ uint32_t found[2], top[2];
-	__shared__ uint16_t upos[EXC ? 2 : 1][EXC ? ROOM : 1];
-	__shared__ C uval[EXC ? 2 : 1][EXC ? ROOM : 1];
+	// exceptions met in the tile; position of the highest, plus one; the list
+	__shared__ uint32_t found, top;
+	__shared__ uint16_t upos[EXC ? ROOM : 1];
+	__shared__ C uval[EXC ? ROOM : 1];
 	const C low = g.nbits >= uint32_t(E::W) ? E::MASK : C((C(1) << (g.nbits % E::W)) - 1);
-	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
 	// (tiles start at multiples of 64 values: 16-byte loads are aligned when src is)
 	const bool wide_ok = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (g.tile_blocks * g.cap) % 64 == 0;
-	int turn = 0;
+	const size_t tile = blockIdx.x;
+	const size_t b0 = tile * g.tile_blocks;
+	const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
+	const size_t v0 = b0 * g.cap;
+	const uint32_t slots = tb * g.cap;
+	const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
+	const bool wide = nvals == slots && slots % PK_VEC == 0 && wide_ok;
+	constexpr int ROUNDS = PK_TILE_VALUES / (PK_THREADS * PK_VEC);
+	uint4 x[ROUNDS];
+	if (wide) {
+		// a full tile: 16 bytes per lane and load, all loads of the tile in
+		// flight before the first is used
+		const uint4 *from = reinterpret_cast<const uint4 *>(src + v0);
+		const uint32_t nvec = slots / PK_VEC;
+#pragma unroll
+		for (int r = 0; r < ROUNDS; r++) {
+			const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
+			x[r] = j < nvec ? from[j] : make_uint4(0, 0, 0, 0);
+		}
+	}
 	if constexpr (EXC) {
-		if (threadIdx.x < 2)
-			found[threadIdx.x] = top[threadIdx.x] = 0;
+		if (threadIdx.x == 0)
+			found = top = 0;
 		__syncthreads();
 	}
-	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, turn ^= 1) {
-		const size_t b0 = tile * g.tile_blocks;
-		const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
-		const size_t v0 = b0 * g.cap;
-		const uint32_t slots = tb * g.cap;
-		const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
-		if (nvals == slots && slots % PK_VEC == 0 && wide_ok) {
-			// a full tile: 16 bytes per lane and load, all loads of the tile in
-			// flight before the first is used
-			constexpr int ROUNDS = PK_TILE_VALUES / (PK_THREADS * PK_VEC);
-			const uint4 *from = reinterpret_cast<const uint4 *>(src + v0);
-			const uint32_t nvec = slots / PK_VEC;
-			uint4 x[ROUNDS];
-			uint32_t nibs[ROUNDS];
+	if (wide) {
+		const uint32_t nvec = slots / PK_VEC;
+		uint32_t nibs[ROUNDS];
+		uint32_t mine = 0;
 #pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
-				x[r] = j < nvec ? from[j] : make_uint4(0, 0, 0, 0);
+		for (int r = 0; r < ROUNDS; r++) {
+			const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
+			C raw[PK_VEC];
+			split16<E>(x[r], raw);
+			uint32_t nib = 0;
+#pragma unroll
+			for (int k = 0; k < PK_VEC; k++) {
+				const C u = value_encode<E, VC>(raw[k], origin);
+				raw[k] = u & low;
+				if constexpr (EXC)
+					nib |= ((u >> g.nbits) != 0 ? 1u : 0u) << k;
 			}
-			uint32_t mine = 0;
+			nibs[r] = j < nvec ? nib : 0u;
+			mine += uint32_t(__popc(nibs[r]));
+			if (j < nvec)
+				join16<E>(raw, reinterpret_cast<uint4 *>(stage) + j);
+		}
+		if constexpr (EXC) {
+			if (mine) {
+				uint32_t slot = atomicAdd(&found, mine);
+				uint32_t hp = 0;
 #pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
-				C raw[PK_VEC];
-				split16<E>(x[r], raw);
-				uint32_t nib = 0;
+				for (int r = 0; r < ROUNDS; r++) {
+					if (nibs[r]) {
+						const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
+						hp = j * PK_VEC + 32u - uint32_t(__clz(nibs[r]));
+						C raw[PK_VEC];
+						split16<E>(x[r], raw);
 #pragma unroll
-				for (int k = 0; k < PK_VEC; k++) {
-					const C u = value_encode<E, VC>(raw[k], origin);
-					raw[k] = u & low;
-					if constexpr (EXC)
-						nib |= ((u >> g.nbits) != 0 ? 1u : 0u) << k;
-				}
-				nibs[r] = j < nvec ? nib : 0u;
-				mine += uint32_t(__popc(nibs[r]));
-				if (j < nvec)
-					join16<E>(raw, reinterpret_cast<uint4 *>(stage) + j);
-			}
-			if constexpr (EXC) {
-				if (mine) {
-					uint32_t slot = atomicAdd(&found[turn], mine);
-					uint32_t hp = 0;
-#pragma unroll
-					for (int r = 0; r < ROUNDS; r++) {
-						if (nibs[r]) {
-							const uint32_t j = threadIdx.x + uint32_t(r) * PK_THREADS;
-							hp = j * PK_VEC + 32u - uint32_t(__clz(nibs[r]));
-							C raw[PK_VEC];
-							split16<E>(x[r], raw);
-#pragma unroll
-							for (int k = 0; k < PK_VEC; k++) {
-								if ((nibs[r] >> k) & 1u) {
-									if (slot < xn.room) {
-										upos[turn][slot] = uint16_t(j * PK_VEC + uint32_t(k));
-										uval[turn][slot] = C(value_encode<E, VC>(raw[k], origin) >> g.nbits);
-									}
-									slot++;
+						for (int k = 0; k < PK_VEC; k++) {
+							if ((nibs[r] >> k) & 1u) {
+								if (slot < xn.room) {
+									upos[slot] = uint16_t(j * PK_VEC + uint32_t(k));
+									uval[slot] = C(value_encode<E, VC>(raw[k], origin) >> g.nbits);
 								}
+								slot++;
 							}
 						}
 					}
-					atomicMax(&top[turn], hp);
 				}
+				atomicMax(&top, hp);
 			}
-		} else {
-			for (uint32_t i = threadIdx.x; i < slots; i += PK_THREADS) {
-				const C u = i < nvals ? value_encode<E, VC>(C(src[v0 + i]), origin) : C(0);
-				stage[i] = S(u & low);
-				if constexpr (EXC) {
-					if ((u >> g.nbits) != 0) {
-						const uint32_t slot = atomicAdd(&found[turn], 1u);
-						atomicMax(&top[turn], i + 1u);
-						if (slot < xn.room) {
-							upos[turn][slot] = uint16_t(i);
-							uval[turn][slot] = C(u >> g.nbits);
-						}
+		}
+	} else {
+		for (uint32_t i = threadIdx.x; i < slots; i += PK_THREADS) {
+			const C u = i < nvals ? value_encode<E, VC>(C(src[v0 + i]), origin) : C(0);
+			stage[i] = S(u & low);
+			if constexpr (EXC) {
+				if ((u >> g.nbits) != 0) {
+					const uint32_t slot = atomicAdd(&found, 1u);
+					atomicMax(&top, i + 1u);
+					if (slot < xn.room) {
+						upos[slot] = uint16_t(i);
+						uval[slot] = C(u >> g.nbits);
 					}
 				}
 			}
 		}
-		__syncthreads();
-		if constexpr (EXC) {
-			// (everybody is done with the other list: it is empty again for the next tile)
-			if (threadIdx.x == 0)
-				found[turn ^ 1] = top[turn ^ 1] = 0;
+	}
+	__syncthreads();
+	for (uint32_t q = threadIdx.x; q < 2 * tb; q += PK_THREADS) {
+		const uint32_t blk = q >> 1, w = q & 1;
+		const S *vals = stage + blk * g.cap;
+		// (chosen between registers: indexed by w, the launch's arguments would
+		// be read from memory)
+		const uint32_t k0 = w ? g.k0[1] : g.k0[0], k1 = w ? g.k1[1] : g.k1[0];
+		uint64_t acc = 0;
+		for (uint32_t k = k0; k <= k1; k++) {
+			const uint64_t val = vals[k];
+			const int pos = int(k * g.nbits) - int(64 * w);
+			acc |= pos >= 0 ? val << pos : val >> (-pos);
 		}
-		for (uint32_t q = threadIdx.x; q < 2 * tb; q += PK_THREADS) {
-			const uint32_t blk = q >> 1, w = q & 1;
-			const S *vals = stage + blk * g.cap;
-			uint64_t acc = 0;
-			for (uint32_t k = g.k0[w]; k <= g.k1[w]; k++) {
-				const uint64_t val = vals[k];
-				const int pos = int(k * g.nbits) - int(64 * w);
-				acc |= pos >= 0 ? val << pos : val >> (-pos);
-			}
-			dst[b0 * 2 + q] = acc;
+		dst[b0 * 2 + q] = acc;
+	}
+	if constexpr (EXC) {
+		const uint32_t count = found;
+		if (threadIdx.x == 0) {
+			xn.counts[tile] = count;
+			xn.last[tile] = top ? v0 + top - 1 : XT_NONE;
 		}
-		__syncthreads();
-		if constexpr (EXC) {
-			const uint32_t count = found[turn];
-			if (threadIdx.x == 0) {
-				xn.counts[tile] = count;
-				xn.last[tile] = top[turn] ? v0 + top[turn] - 1 : XT_NONE;
-			}
-			if (count <= xn.room && threadIdx.x < count) {
-				const size_t at = tile * xn.room + threadIdx.x;
-				xn.spos[at] = upos[turn][threadIdx.x];
-				xn.sval[at] = uint64_t(uval[turn][threadIdx.x]);
-			}
+		if (count <= xn.room && threadIdx.x < count) {
+			const size_t at = tile * xn.room + threadIdx.x;
+			xn.spos[at] = upos[threadIdx.x];
+			xn.sval[at] = uint64_t(uval[threadIdx.x]);
 		}
 	}
 }
@@ -286,169 +280,185 @@ struct patch_plan
 	uint32_t nbits;
 };
 
-// PATCH: bitpfr.h:101-124 in one pass.  While the tile's packed words arrive,
-// the high parts of the tile's exceptions (few) are put at their values' places
-// in an array of LDS that is otherwise zero; every value takes its high part
-// from there as it is unpacked.
-template <typename E, int VC, bool PATCH = false>
+// One tile per workgroup; all of the tile's packed words are asked for at once.
+template <typename E, int VC>
 __global__ __launch_bounds__(PK_THREADS) void k_unpack(const uint4 *src, size_t n, size_t nblk,
 							 pack_geom g, typename E::C origin,
-							 typename E::S *dst, patch_plan plan)
+							 typename E::S *dst)
 {
 	using C = typename E::C;
 	using S = typename E::S;
 	constexpr int PK_VEC = 16 / E::BYTES; // values per 16-byte store
-	// LDS by the launch (unpack_lds_bytes): the tile's packed words, then, with
-	// PATCH, one slot per value of the tile
+	constexpr int ROUNDS = PK_MAX_BLOCKS / PK_THREADS;
+	// LDS by the launch (unpack_lds_bytes): the tile's packed words
+	extern __shared__ __attribute__((aligned(16))) uint32_t unpack_lds[];
+	uint32_t *stage = unpack_lds;
+	// (tiles start at multiples of 64 values: 16-byte stores are aligned when dst is)
+	const bool wide_ok = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0 && (g.tile_blocks * g.cap) % 64 == 0;
+	const size_t tile = blockIdx.x;
+	const size_t b0 = tile * g.tile_blocks;
+	const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
+	const size_t v0 = b0 * g.cap;
+	const uint32_t slots = tb * g.cap;
+	const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
+	uint4 w[ROUNDS];
+#pragma unroll
+	for (int r = 0; r < ROUNDS; r++) {
+		const uint32_t i = threadIdx.x + uint32_t(r) * PK_THREADS;
+		w[r] = i < tb ? src[b0 + i] : make_uint4(0, 0, 0, 0);
+	}
+#pragma unroll
+	for (int r = 0; r < ROUNDS; r++) {
+		const uint32_t i = threadIdx.x + uint32_t(r) * PK_THREADS;
+		if (i < tb)
+			reinterpret_cast<uint4 *>(stage)[i] = w[r];
+	}
+	__syncthreads();
+	if (nvals == slots && slots % PK_VEC == 0 && wide_ok) {
+		// a full tile: every lane makes 16 bytes of consecutive values per store
+		uint4 *to = reinterpret_cast<uint4 *>(dst + v0);
+		for (uint32_t j = threadIdx.x; j < slots / PK_VEC; j += PK_THREADS) {
+			uint32_t blk = __umulhi(j * PK_VEC, g.magic);
+			uint32_t k = j * PK_VEC - blk * g.cap;
+			C v[PK_VEC];
+#pragma unroll
+			for (int t = 0; t < PK_VEC; t++) {
+				const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+				v[t] = value_decode<E, VC>(u, origin) & E::MASK;
+				if (++k == g.cap) {
+					k = 0;
+					blk++;
+				}
+			}
+			join16<E>(v, to + j);
+		}
+	} else {
+		for (uint32_t i = threadIdx.x; i < nvals; i += PK_THREADS) {
+			const uint32_t blk = __umulhi(i, g.magic);
+			const uint32_t k = i - blk * g.cap;
+			const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+			dst[v0 + i] = S(value_decode<E, VC>(u, origin));
+		}
+	}
+}
+
+// bitpfr.h:101-124 in one pass, one tile per workgroup.  While the tile's
+// packed words arrive, the high parts of the tile's exceptions (few) go to
+// their values' places in an array of LDS and are marked in a map with one bit
+// per value; every value whose bit is set takes its high part from there as it
+// is unpacked.
+template <typename E>
+__global__ __launch_bounds__(PK_THREADS) void k_unpack_patch(const uint4 *src, size_t n, size_t nblk,
+							       pack_geom g, typename E::C origin,
+							       typename E::S *dst, patch_plan plan)
+{
+	using C = typename E::C;
+	using S = typename E::S;
+	constexpr int PK_VEC = 16 / E::BYTES; // values per 16-byte store
+	constexpr int ROUNDS = PK_MAX_BLOCKS / PK_THREADS;
+	constexpr int NW = PK_TILE_VALUES / 32;
+	static_assert(NW == 2 * WAVE && 32 % PK_VEC == 0, "two words of the map per lane of the first wavefront");
+	// LDS by the launch (unpack_lds_bytes): the tile's packed words, then one
+	// slot per value of the tile
 	extern __shared__ __attribute__((aligned(16))) uint32_t unpack_lds[];
 	uint32_t *stage = unpack_lds;
 	C *high = reinterpret_cast<C *>(unpack_lds + g.tile_blocks * 4 + 4);
+	__shared__ uint32_t marked[NW];
 	__shared__ uint64_t scan_lds[PK_THREADS / WAVE];
-	const size_t ntiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
-	// (tiles start at multiples of 64 values: 16-byte stores are aligned when dst is)
+	const size_t tile = blockIdx.x;
+	const size_t b0 = tile * g.tile_blocks;
+	const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
+	const size_t v0 = b0 * g.cap;
+	const uint32_t slots = tb * g.cap;
+	const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
 	const bool wide_ok = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0 && (g.tile_blocks * g.cap) % 64 == 0;
-	auto clear_high = [&]() {
-		// (tiles hold a multiple of 64 values)
-		for (uint32_t i = threadIdx.x * PK_VEC; i < g.tile_blocks * g.cap; i += PK_THREADS * PK_VEC)
+	// everything the tile needs from memory is asked for at once
+	uint4 w[ROUNDS];
 #pragma unroll
-			for (int t = 0; t < PK_VEC; t += int(16 / sizeof(C)))
-				*reinterpret_cast<uint4 *>(&high[i + t]) = make_uint4(0, 0, 0, 0);
-	};
-	// What a tile needs to know about its exceptions is asked for two tiles
-	// ahead (the plan) and one tile ahead (the first 64 exceptions themselves,
-	// one per lane of the first wavefront), so that no tile waits for memory
-	// more than once.
-	struct tile_plan
-	{
-		uint64_t lo = 0, hi = 0, where = 0;
-	};
-	tile_plan cur, next;
-	uint64_t ahead_step = 0;
-	C ahead_part = 0;
-	auto fetch_plan = [&](size_t t, tile_plan &tp) {
-		tp = tile_plan();
-		if (t < ntiles) {
-			tp.lo = plan.first[t];
-			tp.hi = plan.first[t + 1];
-			tp.where = plan.where[t];
-		}
-	};
-	auto fetch_entries = [&](const tile_plan &tp) {
-		const uint64_t e = tp.lo + threadIdx.x;
-		const bool take = threadIdx.x < WAVE && e < tp.hi;
-		ahead_step = take && e > tp.lo ? plan.indices[e] + 1 : 0;
-		ahead_part = take ? C(plan.values[e]) << plan.nbits : C(0);
-	};
-	if constexpr (PATCH) {
-		clear_high();
-		fetch_plan(blockIdx.x, cur);
-		fetch_plan(size_t(blockIdx.x) + gridDim.x, next);
-		fetch_entries(cur);
+	for (int r = 0; r < ROUNDS; r++) {
+		const uint32_t i = threadIdx.x + uint32_t(r) * PK_THREADS;
+		w[r] = i < tb ? src[b0 + i] : make_uint4(0, 0, 0, 0);
 	}
-	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		const size_t b0 = tile * g.tile_blocks;
-		const uint32_t tb = uint32_t(nblk - b0 < g.tile_blocks ? nblk - b0 : g.tile_blocks);
-		const size_t v0 = b0 * g.cap;
-		const uint32_t slots = tb * g.cap;
-		const uint32_t nvals = uint32_t(n - v0 < slots ? n - v0 : slots);
-		for (uint32_t i = threadIdx.x; i < tb; i += PK_THREADS)
-			reinterpret_cast<uint4 *>(stage)[i] = src[b0 + i];
-		uint32_t mine = ~0u; // where my exception's high part went
-		bool many = false, shared_restore = false;
-		if constexpr (PATCH) {
-			const uint64_t lo = cur.lo, hi = cur.hi;
-			uint64_t pos = cur.where; // of exception lo
-			const uint64_t step = ahead_step;
-			const C part = ahead_part;
-			cur = next;
-			fetch_plan(tile + 2 * size_t(gridDim.x), next);
-			fetch_entries(cur);
-			if (hi > lo && hi - lo <= uint64_t(WAVE)) {
-				// the usual case, a few exceptions: one wavefront places them,
-				// nobody waits (its own earlier accesses to the array are in order)
-				if (threadIdx.x < WAVE) {
-					const uint64_t e = lo + threadIdx.x;
-					const uint64_t at = pos + wave_scan<uint64_t>(step, 0, [](uint64_t a, uint64_t b) { return a + b; });
-					if (e < hi && at - v0 < uint64_t(slots)) {
-						mine = uint32_t(at - v0);
-						high[mine] = part;
-					}
-				}
-			} else if (hi > lo) {
-				many = hi - lo > uint64_t(PK_THREADS);
-				shared_restore = true;
-				for (uint64_t c = lo; c < hi; c += PK_THREADS) {
-					const uint64_t e = c + threadIdx.x;
-					// steps from exception c to mine
-					const uint64_t step = e < hi && e > c ? plan.indices[e] + 1 : 0;
-					const C part = e < hi ? C(plan.values[e]) << plan.nbits : C(0);
-					uint64_t all;
-					// (the scan synchronises the workgroup: the zeros are in place)
-					const uint64_t at = pos + wg_scan_u64(step, scan_lds, &all);
-					if (e < hi && at - v0 < uint64_t(slots)) {
-						mine = uint32_t(at - v0);
-						high[mine] = part;
-					}
-					// exception c + PK_THREADS sits one more step on
-					pos += all;
-					if (c + PK_THREADS < hi)
-						pos += plan.indices[c + PK_THREADS] + 1;
-				}
-			}
+	// exceptions lo .. hi - 1 are the tile's, exception lo sits at value `first`
+	const uint64_t lo = plan.first[tile], hi = plan.first[tile + 1], first = plan.where[tile];
+	const bool few = hi - lo <= uint64_t(WAVE);
+	// A step of 2^16 or more leads out of the tile whatever it is: cut there,
+	// so that positions inside the tile fit 32 bits.
+	auto step_to = [&](uint64_t e, uint64_t from) {
+		const uint64_t gap = e < hi && e > from ? plan.indices[e] : 0;
+		return e < hi && e > from ? uint32_t(gap < 0xffffu ? gap + 1 : 0x10000u) : 0u;
+	};
+	auto place = [&](uint64_t e, uint32_t rel, C part) {
+		if (e < hi && rel < slots) {
+			atomicOr(&marked[rel / 32], 1u << (rel % 32));
+			high[rel] = part;
 		}
-		__syncthreads();
-		if (nvals == slots && slots % PK_VEC == 0 && wide_ok) {
-			// a full tile: every lane makes 16 bytes of consecutive values per store
-			uint4 *to = reinterpret_cast<uint4 *>(dst + v0);
-			for (uint32_t j = threadIdx.x; j < slots / PK_VEC; j += PK_THREADS) {
-				uint32_t blk = __umulhi(j * PK_VEC, g.magic);
-				uint32_t k = j * PK_VEC - blk * g.cap;
-				C v[PK_VEC], h[PK_VEC] = {};
-				if constexpr (PATCH) {
+	};
+	if (threadIdx.x < WAVE) {
+		marked[2 * threadIdx.x] = 0;
+		marked[2 * threadIdx.x + 1] = 0;
+		if (hi > lo && few && first - v0 < uint64_t(slots)) {
+			// the usual case: the first wavefront places them, one per lane (its
+			// own accesses to LDS are in order)
+			const uint64_t e = lo + threadIdx.x;
+			const uint32_t step = step_to(e, lo);
+			const C part = e < hi ? C(plan.values[e]) << plan.nbits : C(0);
+			const uint32_t rel = uint32_t(first - v0) + wave_scan_sum(step, int(threadIdx.x));
+			wave_sync();
+			place(e, rel, part);
+		}
+	}
 #pragma unroll
-					for (int t = 0; t < PK_VEC; t += int(16 / sizeof(C))) {
-						const uint4 q = *reinterpret_cast<const uint4 *>(&high[j * PK_VEC + t]);
-						if constexpr (sizeof(C) == 8) {
-							h[t] = (uint64_t(q.y) << 32) | q.x;
-							h[t + 1] = (uint64_t(q.w) << 32) | q.z;
-						} else {
-							h[t] = q.x, h[t + 1] = q.y, h[t + 2] = q.z, h[t + 3] = q.w;
-						}
-					}
-				}
+	for (int r = 0; r < ROUNDS; r++) {
+		const uint32_t i = threadIdx.x + uint32_t(r) * PK_THREADS;
+		if (i < tb)
+			reinterpret_cast<uint4 *>(stage)[i] = w[r];
+	}
+	if (hi > lo && !few && first - v0 < uint64_t(slots)) {
+		__syncthreads(); // the map is clear
+		uint32_t at = uint32_t(first - v0); // of exception c
+		for (uint64_t c = lo; c < hi && at < slots; c += PK_THREADS) {
+			const uint64_t e = c + threadIdx.x;
+			const uint32_t step = step_to(e, c);
+			const C part = e < hi ? C(plan.values[e]) << plan.nbits : C(0);
+			uint64_t all;
+			const uint64_t rel = at + wg_scan_u64(step, scan_lds, &all);
+			place(e, uint32_t(rel < 0x7fffffffu ? rel : 0x7fffffffu), part);
+			// exception c + PK_THREADS sits one more step on
+			const uint64_t next = at + all + step_to(c + PK_THREADS, c);
+			at = uint32_t(next < 0x7fffffffu ? next : 0x7fffffffu);
+		}
+	}
+	__syncthreads();
+	if (nvals == slots && slots % PK_VEC == 0 && wide_ok) {
+		// a full tile: every lane makes 16 bytes of consecutive values per store
+		uint4 *to = reinterpret_cast<uint4 *>(dst + v0);
+		for (uint32_t j = threadIdx.x; j < slots / PK_VEC; j += PK_THREADS) {
+			uint32_t blk = __umulhi(j * PK_VEC, g.magic);
+			uint32_t k = j * PK_VEC - blk * g.cap;
+			const uint32_t mine = marked[(j * PK_VEC) / 32] >> ((j * PK_VEC) % 32);
+			C v[PK_VEC];
 #pragma unroll
-				for (int t = 0; t < PK_VEC; t++) {
-					const C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits) | h[t];
-					v[t] = value_decode<E, VC>(u, origin) & E::MASK;
-					if (++k == g.cap) {
-						k = 0;
-						blk++;
-					}
-				}
-				join16<E>(v, to + j);
-			}
-		} else {
-			for (uint32_t i = threadIdx.x; i < nvals; i += PK_THREADS) {
-				const uint32_t blk = __umulhi(i, g.magic);
-				const uint32_t k = i - blk * g.cap;
+			for (int t = 0; t < PK_VEC; t++) {
 				C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
-				if constexpr (PATCH)
-					u |= high[i];
-				dst[v0 + i] = S(value_decode<E, VC>(u, origin));
+				if ((mine >> t) & 1u)
+					u |= high[j * PK_VEC + t];
+				v[t] = value_decode<E, VC_ORIGIN>(u, origin) & E::MASK;
+				if (++k == g.cap) {
+					k = 0;
+					blk++;
+				}
 			}
+			join16<E>(v, to + j);
 		}
-		__syncthreads();
-		if constexpr (PATCH) {
-			// the array is all zeros again for the next tile (whose high parts
-			// go in behind a barrier of their scan)
-			if (many)
-				clear_high();
-			else if (mine != ~0u)
-				high[mine] = C(0);
-			// (zeros written by other wavefronts than the first must be in place
-			// before the first may write the next tile's parts)
-			if (shared_restore)
-				__syncthreads();
+	} else {
+		for (uint32_t i = threadIdx.x; i < nvals; i += PK_THREADS) {
+			const uint32_t blk = __umulhi(i, g.magic);
+			const uint32_t k = i - blk * g.cap;
+			C u = lds_get_bits<C>(stage, blk * 128u + k * g.nbits, g.nbits);
+			if ((marked[i / 32] >> (i % 32)) & 1u)
+				u |= high[i];
+			dst[v0 + i] = S(value_decode<E, VC_ORIGIN>(u, origin));
 		}
 	}
 }
@@ -687,12 +697,6 @@ static size_t unpack_lds_bytes(const pack_geom &g, int dtype, bool patch)
 	return stage + (patch ? size_t(g.tile_blocks) * g.cap * slot + 64 : 0);
 }
 
-static unsigned pack_grid(size_t ntiles)
-{
-	const size_t cap = PACK_GRID_CAP;
-	return unsigned(ntiles < cap ? (ntiles ? ntiles : 1) : cap);
-}
-
 template <int VC>
 static int do_pack(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits, void *dst,
 		   void *stream)
@@ -713,7 +717,9 @@ static int do_pack(int dtype, const void *src, size_t n, uint64_t origin, unsign
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		profile_scope ps(OROCH_K_PACK, st);
-		hipLaunchKernelGGL((k_pack<E, VC>), dim3(pack_grid(ntiles)), dim3(PK_THREADS), 0, st,
+		if (ntiles > 0x7fffffffu)
+			return int(OROCH_E_ARGUMENT);
+		hipLaunchKernelGGL((k_pack<E, VC>), dim3(unsigned(ntiles)), dim3(PK_THREADS), 0, st,
 				   static_cast<const typename E::S *>(src), n, nblk, g,
 				   typename E::C(origin & uint64_t(E::MASK)), static_cast<uint64_t *>(dst));
 		return int(hipGetLastError());
@@ -740,11 +746,13 @@ static int do_unpack(int dtype, const void *src, size_t n, uint64_t origin, unsi
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
 		profile_scope ps(OROCH_K_UNPACK, st);
-		hipLaunchKernelGGL((k_unpack<E, VC>), dim3(pack_grid(ntiles)), dim3(PK_THREADS),
+		if (ntiles > 0x7fffffffu)
+			return int(OROCH_E_ARGUMENT);
+		hipLaunchKernelGGL((k_unpack<E, VC>), dim3(unsigned(ntiles)), dim3(PK_THREADS),
 				   unpack_lds_bytes(g, dtype, false), st,
 				   static_cast<const uint4 *>(src), n, nblk, g,
 				   typename E::C(origin & uint64_t(E::MASK)),
-				   static_cast<typename E::S *>(dst), patch_plan{});
+				   static_cast<typename E::S *>(dst));
 		return int(hipGetLastError());
 	});
 }
@@ -913,7 +921,7 @@ extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_
 	const size_t nblk = (n + g.cap - 1) / g.cap;
 	const size_t ptiles = (nblk + g.tile_blocks - 1) / g.tile_blocks;
 	const uint32_t tile_values = g.tile_blocks * g.cap;
-	if (tile_values < PK_TILE_MIN || tile_values > uint32_t(PK_TILE_VALUES) || tile_values % 64)
+	if (tile_values < PK_TILE_MIN || tile_values > uint32_t(PK_TILE_VALUES) || tile_values % 64 || ptiles > 0x7fffffffu)
 		return OROCH_E_ARGUMENT;
 	const exc_notes xn = {w.counts, w.last, w.spos, w.sval, exc_room(tile_values)};
 	return dispatch_dtype(dtype, [&](auto e) {
@@ -923,7 +931,7 @@ extern "C" int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_
 		const C org = C(origin & uint64_t(E::MASK));
 		{
 			profile_scope ps(OROCH_K_PACK, st);
-			hipLaunchKernelGGL((k_pack<E, VC_ORIGIN, true>), dim3(pack_grid(ptiles)), dim3(PK_THREADS), 0,
+			hipLaunchKernelGGL((k_pack<E, VC_ORIGIN, true>), dim3(unsigned(ptiles)), dim3(PK_THREADS), 0,
 					   st, s, n, nblk, g, org, static_cast<uint64_t *>(dst), xn);
 		}
 		profile_scope ps(OROCH_K_EXCEPT, st);
@@ -1019,7 +1027,9 @@ extern "C" int oroch_bitpfr_decode(int dtype, const void *src, size_t n, uint64_
 		}
 		profile_scope ps(OROCH_K_UNPACK, st);
 		const patch_plan plan = {indices, values, w.plan_first, w.plan_where, nbits};
-		hipLaunchKernelGGL((k_unpack<E, VC_ORIGIN, true>), dim3(pack_grid(ntiles)), dim3(PK_THREADS),
+		if (ntiles > 0x7fffffffu)
+			return int(OROCH_E_ARGUMENT);
+		hipLaunchKernelGGL(k_unpack_patch<E>, dim3(unsigned(ntiles)), dim3(PK_THREADS),
 				   unpack_lds_bytes(g, dtype, true), st,
 				   static_cast<const uint4 *>(src), n, nblk, g, C(origin & uint64_t(E::MASK)),
 				   static_cast<typename E::S *>(dst), plan);
