@@ -44,7 +44,13 @@
 
 namespace oroch_hip {
 
-constexpr int FQ_WORKERS = 12;            // three to a SIMD; the exchanger makes a fourth on one
+#ifndef FQ_NWORKERS
+#define FQ_NWORKERS 12
+#endif
+#ifndef FQ_EU
+#define FQ_EU 4
+#endif
+constexpr int FQ_WORKERS = FQ_NWORKERS;   // three to a SIMD; the exchanger makes a fourth on one
 constexpr int FQ_THREADS = WAVE * (FQ_WORKERS + 1);
 constexpr int FQ_MAX_GROUPS = 256;        // workgroups = entries of a row (one load of 8 bytes per lane)
 constexpr uint32_t FQ_ROW_VALID = 0x8000u;
@@ -466,7 +472,7 @@ __device__ __forceinline__ void fq_exchange(const fq_state &st, fq_mail *mail, u
 }
 
 template <typename E>
-__global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fused_quad(
+__global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(FQ_EU, FQ_EU))) void k_fused_quad(
 	const typename E::S *__restrict__ src, size_t n, size_t nblocks, size_t ntiles,
 	uint8_t *__restrict__ dst, uint64_t *__restrict__ offsets, fq_state st)
 {
@@ -588,7 +594,9 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 	auto is_whole = [&](size_t t) -> bool {
 		return t < ntiles && t * QUAD + QUAD <= nblocks && (t * QUAD + QUAD) * BLOCK <= n;
 	};
-	C v[VPQ], vn[VPQ];
+	// (both start out defined: an array that is only written under a condition
+	// is kept in scratch memory, not in registers)
+	C v[VPQ] = {}, vn[VPQ] = {};
 	if (is_whole(first))
 		load16<E>(src + (first * QUAD + size_t(g)) * BLOCK + size_t(sub) * VPQ, vn);
 	for (uint32_t r = 0; r < rounds; r++) {

@@ -21,11 +21,13 @@
 #include "scan.hpp"
 #include "block.hpp"
 
-// Most workgroups a launch of each block kernel asks for; beyond that a
-// workgroup takes several tiles in turn.  Found by measurement: the decoder
-// of four blocks per wavefront keeps offsets and stream bytes of the tiles
-// ahead in flight and wants long-lived workgroups, the others run faster when
-// the dispatcher replaces short-lived workgroups more often.
+// Most workgroups a launch of each block kernel asks for (grid_for).  Found by
+// measurement: a wavefront should have a few tiles (blocks, or quads of blocks)
+// to walk, so that the fetches ahead of the walk overlap with work; beyond
+// that, more and shorter-lived workgroups let the dispatcher even things out,
+// up to a point that differs per kernel -- the decoder of four blocks per
+// wavefront, which keeps offsets and stream bytes of two tiles in flight, and
+// the selection want longer walks than the encoders.
 #ifndef GRID_SELECT_QUAD
 #define GRID_SELECT_QUAD 16384u
 #endif
@@ -39,7 +41,7 @@
 #define GRID_SELECT 65536u
 #endif
 #ifndef GRID_ENCODE
-#define GRID_ENCODE 65536u
+#define GRID_ENCODE 131072u
 #endif
 #ifndef GRID_DECODE
 #define GRID_DECODE 262144u
@@ -1222,6 +1224,19 @@ static bool one_block_encode_forced()
 
 using namespace oroch_hip;
 
+// Workgroups for a walk over `tiles` tiles: four tiles per wavefront, but at
+// least 16384 workgroups while there is a tile for each of their wavefronts,
+// and at most `most`.
+static unsigned grid_for(size_t tiles, unsigned most)
+{
+	const size_t one_each = (tiles + WAVES_PER_WG - 1) / WAVES_PER_WG;
+	const size_t low = one_each < 16384 ? one_each : 16384;
+	size_t g = one_each / 4;
+	g = g < low ? low : g;
+	g = g < most ? g : most;
+	return unsigned(g ? g : 1);
+}
+
 // Launches the selection pass: four blocks per wavefront for element types up
 // to 32 bits (unless OROCH_OPT_SELECT_ONE_BLOCK is set), one block per wavefront
 // otherwise.
@@ -1232,15 +1247,13 @@ static int launch_select(const void *src, size_t n, size_t nb, oroch_block_desc 
 	if constexpr (sizeof(typename E::C) == 4) {
 		if (!option(OROCH_OPT_SELECT_ONE_BLOCK)) {
 			const size_t nq = (nb + QUAD - 1) / QUAD;
-			unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
-			qgrid = qgrid < GRID_SELECT_QUAD ? qgrid : GRID_SELECT_QUAD;
+			const unsigned qgrid = grid_for(nq, GRID_SELECT_QUAD);
 			hipLaunchKernelGGL(k_select_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 					   static_cast<const typename E::S *>(src), n, nb, desc, sizes);
 			return int(hipGetLastError());
 		}
 	}
-	const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
-	hipLaunchKernelGGL(k_select<E>, dim3(grid < GRID_SELECT ? grid : GRID_SELECT), dim3(WAVE * WAVES_PER_WG), 0, st,
+	hipLaunchKernelGGL(k_select<E>, dim3(grid_for(nb, GRID_SELECT)), dim3(WAVE * WAVES_PER_WG), 0, st,
 			   static_cast<const typename E::S *>(src), n, nb, desc, sizes);
 	return int(hipGetLastError());
 }
@@ -1302,9 +1315,8 @@ extern "C" int oroch_group_stats(int dtype, const void *src, size_t n, oroch_blo
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
-		const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
 		profile_scope ps(OROCH_K_SELECT, st);
-		hipLaunchKernelGGL(k_stats<E>, dim3(grid < GRID_SELECT ? grid : GRID_SELECT), dim3(WAVE * WAVES_PER_WG),
+		hipLaunchKernelGGL(k_stats<E>, dim3(grid_for(nb, GRID_SELECT)), dim3(WAVE * WAVES_PER_WG),
 				   0, st, static_cast<const typename E::S *>(src), n, nb, stats);
 		return int(hipGetLastError());
 	});
@@ -1340,7 +1352,6 @@ static int group_encode_impl(int dtype, const void *src, size_t n, void *dst, si
 	auto two_pass = [&]() {
 		return dispatch_dtype(dtype, [&](auto e) {
 			using E = decltype(e);
-			const unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
 			int r;
 			{
 				profile_scope ps(OROCH_K_SELECT, st);
@@ -1358,15 +1369,14 @@ static int group_encode_impl(int dtype, const void *src, size_t n, void *dst, si
 			if constexpr (sizeof(typename E::C) == 4) {
 				if (!one_block_encode_forced()) {
 					const size_t nq = (nb + QUAD - 1) / QUAD;
-					unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
-					qgrid = qgrid < GRID_ENCODE_QUAD ? qgrid : GRID_ENCODE_QUAD;
+					const unsigned qgrid = grid_for(nq, GRID_ENCODE_QUAD);
 					hipLaunchKernelGGL(k_encode_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 							   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
 							   static_cast<uint8_t *>(dst));
 					return int(hipGetLastError());
 				}
 			}
-			hipLaunchKernelGGL(k_encode<E>, dim3(grid < GRID_ENCODE ? grid : GRID_ENCODE),
+			hipLaunchKernelGGL(k_encode<E>, dim3(grid_for(nb, GRID_ENCODE)),
 					   dim3(WAVE * WAVES_PER_WG), 0, st,
 					   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
 					   static_cast<uint8_t *>(dst));
@@ -1568,17 +1578,13 @@ int oroch_hip::group_decode_within(int dtype, const void *src, const uint64_t *o
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	return dispatch_dtype(dtype, [&](auto e) {
 		using E = decltype(e);
-		unsigned grid = unsigned((nb + WAVES_PER_WG - 1) / WAVES_PER_WG);
-		// more workgroups than the chip holds at once: the dispatcher then
-		// evens out blocks of different cost
-		grid = grid < GRID_DECODE ? grid : GRID_DECODE;
+		const unsigned grid = grid_for(nb, GRID_DECODE);
 		profile_scope ps(OROCH_K_DECODE, st);
 		if constexpr (sizeof(typename E::C) == 4) {
 			if (!one_block_decode_forced()) {
 				// four blocks per wavefront
 				const size_t nq = (nb + QUAD - 1) / QUAD;
-				unsigned qgrid = unsigned((nq + WAVES_PER_WG - 1) / WAVES_PER_WG);
-				qgrid = qgrid < GRID_DECODE_QUAD ? qgrid : GRID_DECODE_QUAD;
+				const unsigned qgrid = grid_for(nq, GRID_DECODE_QUAD);
 				hipLaunchKernelGGL(k_decode_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
 						   static_cast<const uint8_t *>(src), offsets, n, nb, stream_bytes,
 						   static_cast<typename E::S *>(dst));
