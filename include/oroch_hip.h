@@ -136,7 +136,9 @@ int oroch_bitpck_fetch(int dtype, int vcodec, const void *src, size_t n, uint64_
  * (v - origin) >> nbits into values[] (both uint64_t on the device, room for
  * `exc_capacity` entries each).  *nexc (device) receives the number of
  * exceptions found even when it exceeds exc_capacity (nothing is written past
- * the capacity).  workspace: oroch_bitpfr_workspace(n) bytes.
+ * the capacity).  workspace: oroch_bitpfr_workspace(n) bytes of device memory
+ * (about 0.35 bytes per value: per tile of the packer the count and last
+ * position of its exceptions and room for one noted exception per 32 values).
  */
 size_t oroch_bitpfr_workspace(size_t n);
 int oroch_bitpfr_encode(int dtype, const void *src, size_t n, uint64_t origin, unsigned nbits,
