@@ -9,6 +9,8 @@
 //   bitpck.h:171-201, varint.h:85-115      16-byte block unpacking, varints
 #pragma once
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "bitfield.hpp"
 
@@ -90,7 +92,7 @@ __device__ __forceinline__ void store_block(typename E::S *dst, size_t base, int
 {
 	using S = typename E::S;
 	S *p = dst + base + size_t(lane) * VPL;
-	if (lane * VPL + VPL <= nv) {
+	if (nv == BLOCK || lane * VPL + VPL <= nv) {
 		if constexpr (E::BYTES == 8) {
 			ulonglong2 *q = reinterpret_cast<ulonglong2 *>(p);
 			q[0] = make_ulonglong2(v[0], v[1]);
@@ -396,10 +398,20 @@ __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv
 
 // ---- walking the blocks of a stream ------------------------------------------------
 //
-// Persistent wavefronts, each walking blocks wave, wave + stride, ...  The
-// stream offsets are fetched two blocks ahead and the block image one block
-// ahead (into registers), so that the two dependent memory latencies of a
-// block (offset, then bytes) overlap with the decoding of earlier blocks.
+// Wavefronts that walk blocks wave, wave + stride, ...  The stream offsets are
+// fetched two blocks ahead and the block image one block ahead (into
+// registers), so that the two dependent memory latencies of a block (offset,
+// then bytes) overlap with the decoding of earlier blocks.
+//
+// Where the loads are waited for matters.  The compiler's wait counts assume
+// the fewest younger memory operations any path can have issued, so a load
+// under a condition, or stores after a load, turn the wait for that load into
+// a wait for everything in flight.  All loads of the walk are therefore
+// unconditional (clamped addresses: pieces past a block's length read its
+// first piece again and are dropped), and the next block's bytes are awaited
+// and moved to LDS once this block is decoded, ahead of its stores, where the
+// loads for the block after that are issued too: what is younger than those
+// loads at their wait are stores that have had a block's decoding to complete.
 //
 // want(blk, img, len) is asked once the image is in LDS: WALK_DECODE decodes the
 // block and hands the values to sink(blk, nv, v), WALK_SKIP goes on to the
@@ -425,85 +437,126 @@ __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 	uint32_t *img = image[wave];
 	uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
 
-	// Vector loads on purpose: a scalar load would be waited for at the next
-	// LDS access (they share a counter), a vector load stays in flight.
-	auto extent = [&](size_t blk, uint64_t &off, uint64_t &end) {
-		off = 0;
-		end = 0;
-		if (blk < nblocks) {
-			const uint64_t *p = offsets + blk + (lane & 1);
-			const uint64_t x = __builtin_nontemporal_load(p);
-			off = x;
-			end = x;
-		}
-	};
 	// Offsets come from the caller's table and may be anything: every block is
 	// confined to [0, offsets[nblocks]), the length of the stream, and to the
 	// stream_limit of the caller (the size of the memory behind src when the
 	// table comes from a file or the network), so a damaged table yields wrong
 	// values but no read outside the stream.
 	const uint64_t limit = min_u64(uniform(offsets[nblocks]), stream_limit);
-	auto resolve = [&](uint64_t &off, uint64_t end, uint32_t &len) {
-		// lane 0 holds offsets[blk], lane 1 offsets[blk + 1]
-		const uint64_t o = min_u64(read_lane(off, 0), limit) & ~uint64_t(15);
-		const uint64_t e = min_u64(read_lane(end, 1), limit);
+	// a stream without a single 16-byte piece: the loads below go to the table
+	// instead (it has two entries at least) and every block has length zero
+	const uint8_t *bytes = limit >= 16 ? src : reinterpret_cast<const uint8_t *>(offsets);
+	const uint64_t last_piece = limit >= 16 ? (limit - 16) & ~uint64_t(15) : 0;
+
+	// Vector loads on purpose: a scalar load would be waited for at the next
+	// LDS access (they share a counter), a vector load stays in flight.  Lane 0
+	// gets offsets[blk], lane 1 offsets[blk + 1] (both the end of the stream for
+	// blocks past the last).
+	auto extent = [&](size_t blk, uint64_t &o) {
+		size_t i = (blk < nblocks ? blk : nblocks) + size_t(lane & 1);
+		i = i < nblocks ? i : nblocks;
+		o = __builtin_nontemporal_load(offsets + i);
+	};
+	auto resolve = [&](uint64_t x, uint64_t &off, uint32_t &len) {
+		const uint64_t o = min_u64(read_lane(x, 0), limit) & ~uint64_t(15);
+		const uint64_t e = min_u64(read_lane(x, 1), limit);
 		off = o;
 		const uint32_t eh = uint32_t(e >> 32), oh = uint32_t(o >> 32);
 		const bool forward = eh > oh || (eh == oh && uint32_t(e) >= uint32_t(o));
 		len = forward ? clamp_u64(e - o, MAXLEN) : 0u;
 	};
-	auto fetch = [&](uint64_t off, uint32_t len, uint4 (&im)[NCH]) {
-#pragma unroll
-		for (int c = 0; c < NCH; c++) {
-			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
-			im[c] = make_uint4(0, 0, 0, 0);
-			if (o < len)
-				im[c] = *reinterpret_cast<const uint4 *>(src + off + o);
-		}
+	// The bytes in flight, one 1 KiB piece per variable (named variables: as an
+	// array they end up in scratch memory).
+	static_assert(NCH >= 1 && NCH <= 3, "pieces of the longest image");
+	uint4 im0, im1, im2;
+	auto piece = [&](uint64_t off, uint32_t len, int c) {
+		const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+		const uint64_t at = off + (o < len ? o : 0u);
+		return *reinterpret_cast<const uint4 *>(bytes + (at < last_piece ? at : last_piece));
+	};
+	auto fetch = [&](uint64_t off, uint32_t len) {
+		im0 = piece(off, len, 0);
+		if constexpr (NCH > 1)
+			im1 = piece(off, len, 1);
+		if constexpr (NCH > 2)
+			im2 = piece(off, len, 2);
+	};
+	// (the first 16 bytes are parsed as the header whatever the length: zeros
+	// for a block without bytes)
+	auto put = [&](uint32_t len, int c, const uint4 &x) {
+		const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
+		if (o < len)
+			*reinterpret_cast<uint4 *>(img8 + o) = x;
+		else if (o == 0)
+			*reinterpret_cast<uint4 *>(img8) = make_uint4(0, 0, 0, 0);
+	};
+	auto stage = [&](uint32_t len) {
+		put(len, 0, im0);
+		if constexpr (NCH > 1)
+			put(len, 1, im1);
+		if constexpr (NCH > 2)
+			put(len, 2, im2);
 	};
 
 	size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
-	uint64_t off0, off1, off2, end0, end1, end2;
+	// len0: the block staged in LDS; off1/len1 and im: the next block, in
+	// flight; o1: the offsets of the one after it, in flight
+	uint64_t o0, o1, off0, off1;
 	uint32_t len0, len1;
-	uint4 im0[NCH], im1[NCH];
-	extent(blk, off0, end0);
-	extent(blk + stride, off1, end1);
-	resolve(off0, end0, len0);
-	fetch(off0, len0, im0);
-	for (; blk < nblocks; blk += stride) {
-		extent(blk + 2 * stride, off2, end2);
-		resolve(off1, end1, len1);
-		fetch(off1, len1, im1);
-
-		const int nv = block_count(n, blk);
-#pragma unroll
-		for (int c = 0; c < NCH; c++) {
-			const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
-			if (o < len0 || o == 0)
-				*reinterpret_cast<uint4 *>(img8 + o) = im0[c];
-		}
-		wave_sync();
+	extent(blk, o0);
+	extent(blk + stride, o1);
+	resolve(o0, off0, len0);
+	fetch(off0, len0);
+	stage(len0);
+	wave_sync();
+	resolve(o1, off1, len1);
+	fetch(off1, len1);
+	extent(blk + 2 * stride, o1);
+	// moves the next block in and sets the loads for the one after it going
+	auto advance = [&]() {
+		stage(len1);
+		len0 = len1;
+		resolve(o1, off1, len1);
+		fetch(off1, len1);
+		extent(blk + 3 * stride, o1);
+	};
+	// One block: false when the walk is to end.  FULL blocks are the loop's
+	// business, where the number of stores per block is then fixed (see above);
+	// a short last block is taken after the loop.
+	auto step = [&](auto full) -> bool {
+		constexpr bool FULL = decltype(full)::value;
+		const int nv = FULL ? BLOCK : block_count(n, blk);
 		const int w = want(blk, img, len0);
 		if (w == WALK_STOP)
-			break;
+			return false;
 		if (w == WALK_DECODE) {
 			C v[VPL];
-			if (nv == BLOCK)
-				decode_block<E, true>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
-			else
-				decode_block<E, false>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
+			decode_block<E, FULL>(img, len0, nv, lane, vals[wave], gaps[wave], wt, v);
+			wave_sync();
+			advance();
 			sink(blk, nv, v);
+		} else {
+			wave_sync();
+			advance();
 		}
 		wave_sync();
-
-		off0 = off1;
-		len0 = len1;
-		off1 = off2;
-		end1 = end2;
-#pragma unroll
-		for (int c = 0; c < NCH; c++)
-			im0[c] = im1[c];
+		return true;
+	};
+	const size_t nfull = n / BLOCK < nblocks ? n / BLOCK : nblocks;
+	// (the first block apart: the loop is then entered, as it is repeated, with
+	// a block's stores in flight behind the loads, and its waits for the loads
+	// count on them)
+	if (blk < nfull) {
+		if (!step(std::true_type()))
+			return;
+		blk += stride;
 	}
+	for (; blk < nfull; blk += stride) {
+		if (!step(std::true_type()))
+			return;
+	}
+	if (blk < nblocks)
+		step(std::false_type());
 }
 
 } // namespace oroch_hip
