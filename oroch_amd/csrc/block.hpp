@@ -457,13 +457,17 @@ __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 		i = i < nblocks ? i : nblocks;
 		o = __builtin_nontemporal_load(offsets + i);
 	};
+	// (in the two lanes that hold the offsets, not on the scalar unit, which has
+	// the header to parse and is the busier of the two in this loop: 64-bit
+	// minima and comparisons take a dozen scalar instructions each)
 	auto resolve = [&](uint64_t x, uint64_t &off, uint32_t &len) {
-		const uint64_t o = min_u64(read_lane(x, 0), limit) & ~uint64_t(15);
-		const uint64_t e = min_u64(read_lane(x, 1), limit);
-		off = o;
-		const uint32_t eh = uint32_t(e >> 32), oh = uint32_t(o >> 32);
-		const bool forward = eh > oh || (eh == oh && uint32_t(e) >= uint32_t(o));
-		len = forward ? clamp_u64(e - o, MAXLEN) : 0u;
+		uint64_t y = x < limit ? x : limit;      // lane 0: start, lane 1: end
+		y = lane == 0 ? y & ~uint64_t(15) : y;
+		const uint64_t start = dpp_mov<0x111>(uint64_t(0), y); // lane 1 sees lane 0's
+		const uint64_t d = y >= start ? y - start : 0;
+		const uint32_t dl = d < uint64_t(MAXLEN) ? uint32_t(d) : MAXLEN;
+		off = read_lane(y, 0);
+		len = read_lane(dl, 1);
 	};
 	// The bytes in flight, one 1 KiB piece per variable (named variables: as an
 	// array they end up in scratch memory).
@@ -481,21 +485,26 @@ __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 		if constexpr (NCH > 2)
 			im2 = piece(off, len, 2);
 	};
-	// (the first 16 bytes are parsed as the header whatever the length: zeros
-	// for a block without bytes)
-	auto put = [&](uint32_t len, int c, const uint4 &x) {
-		const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
-		if (o < len)
-			*reinterpret_cast<uint4 *>(img8 + o) = x;
-		else if (o == 0)
-			*reinterpret_cast<uint4 *>(img8) = make_uint4(0, 0, 0, 0);
-	};
+	// All pieces go to LDS whatever the block's length, as far as the image has
+	// room (what lies past the block is never looked at, and a store under a
+	// condition that changes from block to block costs more scalar instructions
+	// than the store).  The first 16 bytes are parsed as the header
+	// whatever the length: zeros for a block without bytes.
+	constexpr uint32_t ROOM = uint32_t(image_bytes<E>()); // of the image in LDS
 	auto stage = [&](uint32_t len) {
-		put(len, 0, im0);
-		if constexpr (NCH > 1)
-			put(len, 1, im1);
-		if constexpr (NCH > 2)
-			put(len, 2, im2);
+		const bool none = len == 0;
+		const uint32_t o = uint32_t(lane) * 16u;
+		if (o < ROOM)
+			*reinterpret_cast<uint4 *>(img8 + o) =
+				make_uint4(none ? 0u : im0.x, none ? 0u : im0.y, none ? 0u : im0.z, none ? 0u : im0.w);
+		if constexpr (NCH > 1) {
+			if (1024u + o < ROOM)
+				*reinterpret_cast<uint4 *>(img8 + 1024u + o) = im1;
+		}
+		if constexpr (NCH > 2) {
+			if (2048u + o < ROOM)
+				*reinterpret_cast<uint4 *>(img8 + 2048u + o) = im2;
+		}
 	};
 
 	size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
