@@ -472,18 +472,26 @@ __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 	// The bytes in flight, one 1 KiB piece per variable (named variables: as an
 	// array they end up in scratch memory).
 	static_assert(NCH >= 1 && NCH <= 3, "pieces of the longest image");
-	uint4 im0, im1, im2;
+	uint4 im0, im1 = make_uint4(0, 0, 0, 0), im2 = make_uint4(0, 0, 0, 0);
 	auto piece = [&](uint64_t off, uint32_t len, int c) {
 		const uint32_t o = uint32_t(c) * 1024u + uint32_t(lane) * 16u;
 		const uint64_t at = off + (o < len ? o : 0u);
 		return *reinterpret_cast<const uint4 *>(bytes + (at < last_piece ? at : last_piece));
 	};
+	// (the second and third piece only for blocks that long: a branch on the
+	// length, which is uniform, costs two scalar instructions, a piece some ten
+	// vector ones and a load; the wait for the loads is for all of them at once
+	// anyway, see above)
 	auto fetch = [&](uint64_t off, uint32_t len) {
 		im0 = piece(off, len, 0);
-		if constexpr (NCH > 1)
-			im1 = piece(off, len, 1);
-		if constexpr (NCH > 2)
-			im2 = piece(off, len, 2);
+		if constexpr (NCH > 1) {
+			if (len > 1024u)
+				im1 = piece(off, len, 1);
+		}
+		if constexpr (NCH > 2) {
+			if (len > 2048u)
+				im2 = piece(off, len, 2);
+		}
 	};
 	// All pieces go to LDS whatever the block's length, as far as the image has
 	// room (what lies past the block is never looked at, and a store under a
@@ -498,11 +506,11 @@ __device__ __forceinline__ void walk_blocks(const uint8_t *__restrict__ src,
 			*reinterpret_cast<uint4 *>(img8 + o) =
 				make_uint4(none ? 0u : im0.x, none ? 0u : im0.y, none ? 0u : im0.z, none ? 0u : im0.w);
 		if constexpr (NCH > 1) {
-			if (1024u + o < ROOM)
+			if (len > 1024u && 1024u + o < ROOM)
 				*reinterpret_cast<uint4 *>(img8 + 1024u + o) = im1;
 		}
 		if constexpr (NCH > 2) {
-			if (2048u + o < ROOM)
+			if (len > 2048u && 2048u + o < ROOM)
 				*reinterpret_cast<uint4 *>(img8 + 2048u + o) = im2;
 		}
 	};
