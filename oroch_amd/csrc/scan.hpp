@@ -97,18 +97,48 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_tile_offsets(const In *items, 
 	const size_t base = size_t(blockIdx.x) * SCAN_TILE + size_t(threadIdx.x) * SCAN_ITEMS;
 	uint64_t x[SCAN_ITEMS];
 	uint64_t s = 0;
+	// a thread's eight items and eight offsets in 16-byte accesses where the
+	// arrays allow (whole tiles, 16-byte aligned)
+	const bool whole = base + SCAN_ITEMS <= n;
+	bool wide_in = false;
+	if constexpr (sizeof(In) == 4 && SCAN_ITEMS == 8)
+		wide_in = whole && (reinterpret_cast<uintptr_t>(items) & 15u) == 0;
+	if (wide_in) {
+		const uint4 *q = reinterpret_cast<const uint4 *>(items + base);
+		const uint4 a = q[0], b = q[1];
+		const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-	for (int i = 0; i < SCAN_ITEMS; i++) {
-		x[i] = base + i < n ? uint64_t(items[base + i]) + ADD : 0u;
-		s += x[i];
+		for (int i = 0; i < SCAN_ITEMS; i++) {
+			x[i] = uint64_t(d[i]) + ADD;
+			s += x[i];
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < SCAN_ITEMS; i++) {
+			x[i] = base + i < n ? uint64_t(items[base + i]) + ADD : 0u;
+			s += x[i];
+		}
 	}
 	uint64_t all;
 	uint64_t run = tile_base[blockIdx.x] + wg_scan_u64(s, lds, &all) - s;
+	if (whole && (reinterpret_cast<uintptr_t>(offsets) & 15u) == 0) {
+		uint64_t o[SCAN_ITEMS];
 #pragma unroll
-	for (int i = 0; i < SCAN_ITEMS; i++) {
-		if (base + i < n)
-			offsets[base + i] = run;
-		run += x[i];
+		for (int i = 0; i < SCAN_ITEMS; i++) {
+			o[i] = run;
+			run += x[i];
+		}
+		uint4 *to = reinterpret_cast<uint4 *>(offsets + base);
+#pragma unroll
+		for (int i = 0; i < SCAN_ITEMS; i += 2)
+			to[i / 2] = make_uint4(uint32_t(o[i]), uint32_t(o[i] >> 32), uint32_t(o[i + 1]), uint32_t(o[i + 1] >> 32));
+	} else {
+#pragma unroll
+		for (int i = 0; i < SCAN_ITEMS; i++) {
+			if (base + i < n)
+				offsets[base + i] = run;
+			run += x[i];
+		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 		offsets[n] = *total;
