@@ -562,13 +562,31 @@ __global__ __launch_bounds__(XL_THREADS) void k_exc_lists(const typename E::S *s
 		return;
 	if (tile + 1 == ntiles && lane == 0)
 		*nexc = rank_base[ntiles];
-	const uint32_t count = uniform(xn.counts[tile]);
+	// Everything the tile may need from memory is asked for at once (one wait
+	// instead of a chain of them): its count and rank, the last positions of the
+	// 64 tiles before it, and its first notes, whether they turn out to be
+	// wanted or not (what lies past the count is never looked at).
+	const uint32_t count_l = xn.counts[tile];
+	const uint64_t rank0 = rank_base[tile];
+	const size_t lo0 = tile > WAVE ? tile - WAVE : 0;
+	const uint64_t near = lo0 + size_t(lane) < tile ? xn.last[lo0 + size_t(lane)] : XT_NONE;
+	const uint16_t *spos = xn.spos + tile * xn.room;
+	const uint64_t *sval = xn.sval + tile * xn.room;
+	const uint32_t e1 = uint32_t(lane) + WAVE < xn.room ? uint32_t(lane) + WAVE : xn.room - 1u;
+	uint32_t p[2] = {spos[lane], spos[e1]}, r[2];
+	uint64_t hv[2] = {sval[lane], sval[e1]};
+	const uint32_t count = uniform(count_l);
 	if (count == 0)
 		return;
 	// The last exception before this tile: the nearest earlier tile that has
 	// one, 64 tiles per step.
 	uint64_t before = XT_NONE;
-	for (size_t hi = tile; hi > 0 && before == XT_NONE;) {
+	{
+		const uint64_t have = __ballot(near != XT_NONE);
+		if (have)
+			before = read_lane(near, 63 - __builtin_clzll(have));
+	}
+	for (size_t hi = lo0; hi > 0 && before == XT_NONE;) {
 		const size_t lo = hi > WAVE ? hi - WAVE : 0;
 		const size_t t = lo + size_t(lane);
 		const uint64_t x = t < hi ? xn.last[t] : XT_NONE;
@@ -578,7 +596,6 @@ __global__ __launch_bounds__(XL_THREADS) void k_exc_lists(const typename E::S *s
 		hi = lo;
 	}
 	const uint64_t v0 = uint64_t(tile) * tile_values;
-	const uint64_t rank0 = rank_base[tile];
 	// the position a gap counts from: one past the exception before, 0 at the start
 	const uint64_t next0 = before == XT_NONE ? 0 : before + 1;
 	if (count <= xn.room) {
@@ -587,20 +604,13 @@ __global__ __launch_bounds__(XL_THREADS) void k_exc_lists(const typename E::S *s
 		static_assert(XL_ROOM == 2 * WAVE && XL_MAP == 2 * WAVE, "two entries and two words of the map per lane");
 		uint32_t *map = maps[threadIdx.x / WAVE], *under = unders[threadIdx.x / WAVE];
 		uint16_t *sorted = sorteds[threadIdx.x / WAVE];
-		const uint16_t *spos = xn.spos + tile * xn.room;
-		const uint64_t *sval = xn.sval + tile * xn.room;
 		map[2 * lane] = map[2 * lane + 1] = 0;
 		wave_sync();
-		uint32_t p[2] = {0, 0}, r[2];
-		uint64_t hv[2] = {0, 0};
 #pragma unroll
 		for (int t = 0; t < 2; t++) {
 			const uint32_t e = uint32_t(lane) + uint32_t(t) * WAVE;
-			if (e < count) {
-				p[t] = spos[e];
-				hv[t] = sval[e];
+			if (e < count)
 				atomicOr(&map[p[t] / 32], 1u << (p[t] % 32));
-			}
 		}
 		wave_sync();
 		{
