@@ -235,6 +235,29 @@ def test_bitpfr_lists_mixed_density(hip, oracle, dt):
     assert np.array_equal(host(val).astype(np.uint64)[:1000], ev[:1000])
 
 
+@pytest.mark.parametrize("nblocks", [1, 7, 2047, 2048, 2049, 5000])
+def test_offsets_table_at_any_8_byte_address(hip, oracle, nblocks):
+    # the offsets scan writes 16 bytes at a time where the table's address allows and
+    # 8 bytes at a time elsewhere; tables on either side of a tile of the scan (2048 blocks),
+    # a short last block, and the table handed back to the decoder from the same address
+    import torch
+
+    n = nblocks * 256 - 56
+    a = dg.outlier_mix(n, np.int32, seed=23, shift=-200)
+    x = dev(a)
+    exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+    enc = hip.GroupEncoder(x.dtype, n, x.device)
+    for shift in (0, 1):
+        table = torch.zeros(nblocks + 2, dtype=torch.int64, device=x.device)
+        enc.offsets = table[shift:shift + nblocks + 1]
+        assert enc.offsets.data_ptr() % 16 == 8 * shift
+        total = enc.encode(x, want_total=True)
+        assert total == exp.size
+        assert np.array_equal(host(enc.offsets).astype(np.uint64), exp_offs)
+        assert np.array_equal(host(enc.out[:total]), exp)
+        assert np.array_equal(host(hip.group_decode(enc.out[:total], enc.offsets, n, np.int32)), a)
+
+
 def test_headline_distribution_round_trip(hip, oracle):
     # the bench workload at a size the oracle still checks byte for byte
     n = 256 * 4096
