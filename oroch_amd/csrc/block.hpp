@@ -339,8 +339,10 @@ __device__ __forceinline__ void decode_block(uint32_t *img, uint32_t len, int nv
 					if (e < nout) {
 						if (inb) {
 							const uint32_t bk = __umulhi(e, imagic);
-							step = uint32_t(lds_get_bits64(img, ibase * 8u + bk * 128u +
-												    (e - bk * icap) * inb, inb));
+							// (gaps inside a block fit 32 bits; wider fields only
+							// in streams no encoder made)
+							const uint32_t at = ibase * 8u + bk * 128u + (e - bk * icap) * inb;
+							step = inb <= 32u ? lds_get_bits32(img, at, inb) : uint32_t(lds_get_bits64(img, at, inb));
 						} else {
 							step = gp[e];
 						}
