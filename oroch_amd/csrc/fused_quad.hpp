@@ -543,6 +543,11 @@ __global__ __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_waves_per_eu(FQ_E
 	uint32_t flushed = 0, wpos = 0; // rounds copied out; where the next image goes
 	// copies the oldest tile (round `flushed`) out at its offset and records where its blocks start
 	auto flush = [&]() {
+#ifdef FQ_WAIT_LOADS
+		// the values asked for ahead must have arrived before anything is stored:
+		// behind the stores they would wait for the stores to be acknowledged
+		__builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+#endif
 		const uint32_t slot = flushed % uint32_t(FQ_QDEPTH);
 		const size_t t = first + size_t(flushed) * per_round;
 		const uint64_t base = uniform(mail.base[slot][wave]);

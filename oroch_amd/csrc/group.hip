@@ -32,6 +32,9 @@
 #ifndef GRID_SELECT_QUAD
 #define GRID_SELECT_QUAD 16384u
 #endif
+#ifndef GRID_SELECT_OCTO
+#define GRID_SELECT_OCTO 16384u
+#endif
 #ifndef GRID_ENCODE_QUAD
 #define GRID_ENCODE_QUAD 65536u
 #endif
@@ -1057,6 +1060,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) DECODE_BLOCK_ATTR void k_decode
 #include "encode_quad.hpp"
 #include "select_quad.hpp"
 #include "fused_quad.hpp"
+#include "octo.hpp"
 
 namespace oroch_hip {
 
@@ -1085,6 +1089,10 @@ struct group_ws
 	uint32_t *fq_abort;
 	fq_state fq;
 	size_t fq_bytes, fq_rows;
+	// eight blocks per wavefront, single launch: abort word and table (one memset)
+	uint32_t *oc_abort;
+	oc_state oc;
+	size_t oc_bytes, oc_rows;
 	size_t bytes;
 };
 
@@ -1123,6 +1131,17 @@ static group_ws carve_ws(void *ws, size_t n)
 		w.fq_rows = max_rounds;
 		w.fq_bytes = 128 + max_rounds * FQ_MAX_GROUPS * sizeof(uint16_t);
 		off = align_up(off + w.fq_bytes, 256);
+	}
+	{
+		// the same table for the launch of eight blocks per wavefront
+		const size_t ntiles = (nb + OCT - 1) / OCT;
+		const size_t max_rounds = ntiles / (size_t(OC_WORKERS) * 64) + 2;
+		w.oc_abort = reinterpret_cast<uint32_t *>(p + off);
+		w.oc.abort_flag = w.oc_abort;
+		w.oc.rows = reinterpret_cast<uint16_t *>(p + off + 128);
+		w.oc_rows = max_rounds;
+		w.oc_bytes = 128 + max_rounds * OC_MAX_GROUPS * sizeof(uint16_t);
+		off = align_up(off + w.oc_bytes, 256);
 	}
 	w.bytes = off;
 	return w;
@@ -1196,7 +1215,22 @@ static int launch_select(const void *src, size_t n, size_t nb, oroch_block_desc 
 			 hipStream_t st)
 {
 	if constexpr (sizeof(typename E::C) == 4) {
-		if (!option(OROCH_OPT_SELECT_ONE_BLOCK)) {
+		if (option(OROCH_OPT_SELECT_ONE_BLOCK) == 2 && n / (size_t(OCT) * BLOCK) > 0) {
+			// eight blocks per wavefront for the full octets, the rest one by one
+			const size_t noct = n / (size_t(OCT) * BLOCK);
+			hipLaunchKernelGGL(k_select_octo<E>, dim3(grid_for(noct, GRID_SELECT_OCTO)),
+					   dim3(WAVE * WAVES_PER_WG), 0, st, static_cast<const typename E::S *>(src),
+					   noct, desc, sizes);
+			const size_t done = noct * OCT;
+			if (done < nb)
+				hipLaunchKernelGGL(k_select<E>, dim3(grid_for(nb - done, GRID_SELECT)),
+						   dim3(WAVE * WAVES_PER_WG), 0, st,
+						   static_cast<const typename E::S *>(src) + done * BLOCK,
+						   n - done * BLOCK, nb - done, desc ? desc + done : nullptr,
+						   sizes ? sizes + done : nullptr);
+			return int(hipGetLastError());
+		}
+		if (option(OROCH_OPT_SELECT_ONE_BLOCK) != 1) {
 			const size_t nq = (nb + QUAD - 1) / QUAD;
 			const unsigned qgrid = grid_for(nq, GRID_SELECT_QUAD);
 			hipLaunchKernelGGL(k_select_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
@@ -1403,9 +1437,58 @@ static int group_encode_impl(int dtype, const void *src, size_t n, void *dst, si
 			}
 		});
 	};
+	auto fused_octo = [&]() {
+		return dispatch_dtype(dtype, [&](auto e) {
+			using E = decltype(e);
+			if constexpr (sizeof(typename E::C) == 4) {
+				const size_t ntiles = (nb + OCT - 1) / OCT;
+				const int resident = oc_resident_workgroups<E>();
+				// (tiles that are not whole read the first tile's values in passing)
+				if (resident <= 0 || n < size_t(OCT) * BLOCK)
+					return two_pass();
+				const size_t want = (ntiles + OC_WORKERS - 1) / OC_WORKERS;
+				const unsigned grid = unsigned(want < size_t(resident) ? want : size_t(resident));
+				const size_t per_round = size_t(grid) * OC_WORKERS;
+				if ((ntiles + per_round - 1) / per_round > w.oc_rows)
+					return two_pass();
+				int r = int(hipMemsetAsync(w.oc_abort, 0, w.oc_bytes, st));
+				if (r)
+					return r;
+				{
+					profile_scope ps(OROCH_K_ENCODE, st);
+					hipLaunchKernelGGL(k_fused_octo<E>, dim3(grid), dim3(OC_THREADS), 0, st,
+							   static_cast<const typename E::S *>(src), n, nb, ntiles,
+							   static_cast<uint8_t *>(dst), offsets, w.oc);
+					r = int(hipGetLastError());
+				}
+				if (r)
+					return r;
+#ifdef OC_STATS
+				{
+					unsigned long long h[16];
+					(void) hipDeviceSynchronize();
+					(void) hipMemcpyFromSymbol(h, HIP_SYMBOL(oc_stats), sizeof h);
+					const double t = double(h[8] ? h[8] : 1);
+					fprintf(stderr, "octo: %llu tiles, cycles per tile: wait for values %.0f, select %.0f, prepare %.0f, wait for writer %.0f, pack %.0f, all %.0f\n",
+						h[8], h[0] / t, h[1] / t, h[2] / t, h[3] / t, h[4] / t, h[5] / t);
+					unsigned long long z[16] = {0};
+					(void) hipMemcpyToSymbol(HIP_SYMBOL(oc_stats), z, sizeof z);
+				}
+#endif
+				hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, st, w.oc_abort, offsets, nb);
+				return int(hipGetLastError());
+			} else {
+				return two_pass();
+			}
+		});
+	};
 	const int path = option(OROCH_OPT_ENCODE_PATH);
-	const bool force_two_pass = path != 2 && path != 3;
-	rc = force_two_pass ? two_pass() : path == 3 ? fused_quad() : single_pass();
+	// A single launch that gives up leaves ~0 as the stream length, which only a
+	// caller that reads the length back can notice and repair: the others
+	// (the entry point that allocates nothing, the host pipeline) always take
+	// the separate launches.
+	const bool force_two_pass = (path != 2 && path != 3 && path != 4) || !total_host;
+	rc = force_two_pass ? two_pass() : path == 4 ? fused_octo() : path == 3 ? fused_quad() : single_pass();
 	if (rc == 0 && total_host && !force_two_pass) {
 		// the only place the host can see that the single-pass kernel gave up
 		uint64_t total = 0;
