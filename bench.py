@@ -61,7 +61,66 @@ def gen_outlier_mix_torch(n, seed, device, body_bits=10, out_bits=28, permille=1
     return out
 
 
-def cpu_baseline(log2n, seed, config="headline"):
+def cpu_info():
+    """Model name of the host CPU, the machine's logical CPUs and the share of
+    them this process may use."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    # the GPU box hands a one-GPU job 16 of the machine's CPUs and says so in
+    # OMP_NUM_THREADS; the affinity mask there still shows the whole machine
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or affinity
+    return model, os.cpu_count(), max(1, min(share, affinity))
+
+
+def cpu_blocks(po, a, threads):
+    """select + encode + decode of blocks of 256 by the reference's own code,
+    one thread and `threads` threads over disjoint block ranges; best of 2."""
+    def run(t):
+        best = None
+        for _ in range(2):
+            r = po.ref.bench_blocks(a, 256, t)
+            assert r[4] == 1.0, "reference round trip failed"
+            if best is None or r[:3].sum() < best[:3].sum():
+                best = r
+        return best
+    one, many = run(1), run(threads)
+    gbs = lambda r: 2 * a.nbytes / r[:3].sum() / 1e9
+    return {"value": gbs(many), "value_1thread": gbs(one),
+            "phases_1thread_GBps": {"select": a.nbytes / one[0] / 1e9, "encode": a.nbytes / one[1] / 1e9,
+                                    "decode": a.nbytes / one[2] / 1e9}}
+
+
+def cpu_whole_arrays(po, dg):
+    """The whole-sequence codecs with the caller's parameters (the reference's
+    bitpck.h / bitfor.h / bitpfr.h on one thread), the distributions of the
+    configurations at 2^24 values: GB/s of uncompressed bytes."""
+    n = 1 << 24
+    out = {}
+    a = dg.uniform_bits(n, np.uint32, 1, 13)
+    cases = [("bitpck uint32 13 bits", a, 0, 0, 13)]
+    a = dg.uniform_bits(n, np.int32, 2, 16, shift=-20000 + 1000000)
+    cases.append(("bitfor int32 16 bits", a, 1, int(a.min()), 16))
+    a = dg.outlier_mix(n, np.uint32, 3)
+    cases.append(("bitpfr uint32 10 bits + 1% outliers", a, 2, 0, 10))
+    for name, a, kind, origin, nbits in cases:
+        best = None
+        for _ in range(2):
+            r = po.ref.bench_whole(a, kind, origin, nbits)
+            assert r[2] == 1.0, "reference round trip failed"
+            if best is None or r[:2].sum() < best[:2].sum():
+                best = r
+        out[name] = {"encode_GBps": a.nbytes / best[0] / 1e9, "decode_GBps": a.nbytes / best[1] / 1e9}
+    return out
+
+
+def cpu_baseline(log2n, seed, config="headline", native_child=False):
     """The reference's own code (oracle/_ref) -- or the C port -- on host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import datagen as dg
@@ -74,29 +133,47 @@ def cpu_baseline(log2n, seed, config="headline"):
         a = dg.outlier_mix(n, np.int32, seed=seed, shift=-200)
     name = str(a.dtype)
     nbytes = a.nbytes
-    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, share)
-    threads = max(1, min(threads, share))
+    model, nproc, threads = cpu_info()
     if po.ref is not None:
-        def run(t):
-            best = None
-            for _ in range(2):
-                r = po.ref.bench_blocks(a, 256, t)
-                assert r[4] == 1.0, "reference round trip failed"
-                if best is None or r[:3].sum() < best[:3].sum():
-                    best = r
-            return best
-        one, many = run(1), run(threads)
-        gbs = lambda r: 2 * nbytes / r[:3].sum() / 1e9
-        return {
-            "value": gbs(many), "unit": "GB/s", "cores": threads, "kind": "reference",
-            "value_1thread": gbs(one),
-            "phases_1thread_GBps": {"select": nbytes / one[0] / 1e9, "encode": nbytes / one[1] / 1e9,
-                                    "decode": nbytes / one[2] / 1e9},
+        res = cpu_blocks(po, a, threads)
+        if native_child:
+            return res
+        out = {
+            "value": res["value"], "unit": "GB/s", "cores": threads, "kind": "reference",
+            "cpu_model": model, "nproc": nproc,
+            "value_1thread": res["value_1thread"], "phases_1thread_GBps": res["phases_1thread_GBps"],
+            "whole_array_1thread_GBps": cpu_whole_arrays(po, dg),
             "sample": "2^%d %s values of the bench distribution, blocks of 256, select+encode+"
-                      "decode by the reference headers (g++ -O2), best of 2, %d std::threads "
-                      "over disjoint block ranges" % (log2n, name, threads),
+                      "decode by the reference headers (g++ -O2), best of 2, %d std::threads over "
+                      "disjoint block ranges: every CPU this job may use (the machine has %d, a "
+                      "one-GPU job's share is what OMP_NUM_THREADS says); whole_array: the "
+                      "reference's bitpck / bitfor / bitpfr with the caller's parameters on 2^24 "
+                      "values, one thread" % (log2n, name, threads, nproc),
         }
+        # the same at -O3 -march=native of the machine that built the checker, in
+        # a child process: a host without those instructions only loses this figure
+        native = os.path.join(ROOT, "oracle", "_ref", "liboroch_ref_native.so")
+        if os.path.exists(native):
+            import subprocess
+
+            arch = "unknown"
+            try:
+                arch = open(os.path.join(ROOT, "oracle", "_ref", "native_arch.txt")).read().strip()
+            except OSError:
+                pass
+            env = dict(os.environ, OROCH_REF_LIBRARY=os.path.join("_ref", "liboroch_ref_native.so"))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-native-child",
+                                "--cpu-log2n", str(min(log2n, 26)), "--config", config],
+                               env=env, capture_output=True, text=True, timeout=300)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                out["O3_march_native"] = dict(json.loads(lines[-1]), built_for=arch,
+                                              sample="2^%d values, otherwise as above" % min(log2n, 26))
+            else:
+                out["O3_march_native"] = {"value": None, "built_for": arch,
+                                          "note": "did not run on this host (exit %d): built for another "
+                                                  "CPU" % r.returncode}
+        return out
     o = po.oracle
     t0 = time.perf_counter()
     stream, offs = o.blocks_encode(a, 256, 16)
@@ -105,6 +182,7 @@ def cpu_baseline(log2n, seed, config="headline"):
     t2 = time.perf_counter()
     assert np.array_equal(back, a)
     return {"value": 2 * nbytes / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+            "cpu_model": model, "nproc": nproc,
             "sample": "2^%d %s values of the bench distribution through the C restatement "
                       "(encode %.2fs, decode %.2fs)" % (log2n, name, t1 - t0, t2 - t1)}
 
@@ -112,18 +190,24 @@ def cpu_baseline(log2n, seed, config="headline"):
 def measured_traffic(direction, log2n):
     """HBM bytes per step of one direction ("encode": every kernel of the
     encode path, "decode": the decode kernel) from the committed PMC passes
-    (rocprofv3 cannot run inside this process), and the commit whose kernels
-    were measured; only valid for the workload they were collected on."""
+    (rocprofv3 cannot run inside this process), only for the workload they were
+    collected on and only while the kernel sources are still the ones they were
+    measured on: returns (bytes or None, what the record says about itself)."""
+    import oroch_amd.sources as sources
+
     path = os.path.join(ROOT, "profiles", "traffic_int32_2p30.json")
     if log2n != 30 or not os.path.exists(path):
         return None, None
     rec = json.load(open(path))
     k = rec.get("kernels", {})
-    if not k:
-        return None, None
+    about = {"commit": rec.get("commit"), "kernel_sources": rec.get("kernel_sources"),
+             "kernel_sources_now": sources.digest()}
+    if not k or about["kernel_sources"] != about["kernel_sources_now"]:
+        about["stale"] = True
+        return None, about
     decode = sum(v["total_bytes"] for name, v in k.items() if "decode" in name)
     encode = sum(v["total_bytes"] for name, v in k.items() if "decode" not in name)
-    return (decode if direction == "decode" else encode), rec.get("commit")
+    return (decode if direction == "decode" else encode), about
 
 
 def end_to_end(x_dev, n):
@@ -188,6 +272,118 @@ def end_to_end(x_dev, n):
                     "larger share host to device, decode the other way round"}
 
 
+def kernel_ms(fn, steps):
+    """Device time of the library's kernels per call of fn, summed over the
+    kernels it launches (HIP events on the launch stream)."""
+    import torch
+
+    import oroch_amd
+
+    fn()
+    torch.cuda.synchronize()
+    oroch_amd.profile_start(64 * (steps + 1))
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    prof = oroch_amd.profile_stop()
+    return {k: ms / cnt for k, (ms, cnt) in prof.items()}
+
+
+def other_configs(device, steps=5, shrink=0):
+    """The other BASELINE configurations at their full sizes on this GPU: kernel
+    time per direction, algorithmic bytes (values once + code once) and the
+    fraction of 8 TB/s that makes; every one round-trip-checked."""
+    import torch
+
+    import oroch_amd as hip
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import devgen
+
+    out = {}
+    size = lambda log2n: 1 << max(12, log2n - shrink)  # (smaller for the tests of this script)
+
+    def entry(name, raw, coded, enc, dec, extra=None):
+        e = {"values_bytes": raw, "code_bytes": coded, "algorithmic_bytes": raw + coded,
+             "encode_kernel_ms": enc, "decode_kernel_ms": dec,
+             "encode_ms": sum(enc.values()), "decode_ms": sum(dec.values())}
+        for d in ("encode", "decode"):
+            e[d + "_frac"] = (raw + coded) / (e[d + "_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        e["round_trip"] = "ok"
+        if extra:
+            e.update(extra)
+        out[name] = e
+
+    def group(name, x, np_dtype):
+        n = x.numel()
+        enc = hip.GroupEncoder(np_dtype, n, device)
+        back = torch.empty_like(x)
+        code = hip.dtype_code(np_dtype)
+
+        def decode():
+            rc = hip.lib.oroch_group_decode(code, enc.out.data_ptr(), enc.offsets.data_ptr(), n, back.data_ptr(),
+                                            hip.capi._stream())
+            if rc:
+                raise SystemExit("decode failed: %d" % rc)
+        e = kernel_ms(lambda: enc.encode(x), steps)
+        d = kernel_ms(decode, steps)
+        if not torch.equal(back.view(torch.uint8), x.view(torch.uint8)):
+            raise SystemExit("round trip mismatch in " + name)
+        total = int(enc.offsets[-1].item())
+        entry(name, x.numel() * x.element_size(), total, e, d, {"compressed_over_raw": total / (n * x.element_size())})
+
+    # configuration 2: int32, 2^26 values, zigzag bit-packing and frame of reference
+    n = size(26)
+    x = devgen.uniform_bits(n, torch.int32, 2, 16, device, shift=-20000 + 1000000)
+    lo, hi = int(x.min()), int(x.max())
+    zz = max((lo << 1) ^ (lo >> 31), (hi << 1) ^ (hi >> 31)) & 0xffffffff
+    nb_pck, nb_for = zz.bit_length(), (hi - lo).bit_length()
+    keep = {}
+    e = kernel_ms(lambda: keep.__setitem__("p", hip.bitpck_encode(x, nb_pck)), steps)
+    d = kernel_ms(lambda: keep.__setitem__("b", hip.bitpck_decode(keep["p"], n, nb_pck, np.int32)), steps)
+    if not torch.equal(keep["b"], x):
+        raise SystemExit("round trip mismatch in bitpck")
+    entry("config2 bitpck int32 2^26 (zigzag, %d bits)" % nb_pck, 4 * n, keep["p"].numel(), e, d)
+    e = kernel_ms(lambda: keep.__setitem__("p", hip.bitfor_encode(x, lo, nb_for)), steps)
+    d = kernel_ms(lambda: keep.__setitem__("b", hip.bitfor_decode(keep["p"], n, lo, nb_for, np.int32)), steps)
+    if not torch.equal(keep["b"], x):
+        raise SystemExit("round trip mismatch in bitfor")
+    entry("config2 bitfor int32 2^26 (origin = min, %d bits)" % nb_for, 4 * n, keep["p"].numel(), e, d)
+    keep.clear()
+    del x
+
+    # configuration 3: uint32, 2^28 values, 1 % outliers, one patched code over the whole array
+    n = size(28)
+    xs = devgen.outlier_mix(n, torch.int32, 3, device)
+    xu = xs.view(torch.uint32)
+    e = kernel_ms(lambda: keep.__setitem__("c", hip.bitpfr_encode(xu, 0, 10, capacity=n // 64)), steps)
+    b, idx, val, nexc = keep["c"]
+    d = kernel_ms(lambda: keep.__setitem__("b", hip.bitpfr_decode(b, n, 0, 10, idx, val, np.uint32)), steps)
+    if not torch.equal(keep["b"].view(torch.int32), xs):
+        raise SystemExit("round trip mismatch in bitpfr")
+    entry("config3 bitpfr uint32 2^28 (origin 0, 10 bits, whole array)", 4 * n, b.numel() + 16 * int(nexc), e, d,
+          {"exceptions": int(nexc)})
+    keep.clear()
+    del b, idx, val
+    group("config3 per-block selection uint32 2^28", xu, np.uint32)
+    del xs, xu
+
+    # configuration 5: int16 and uint64 through integer_group
+    x = devgen.outlier_mix(size(28), torch.int16, 5, device, body_bits=9, out_bits=16, permille=5, shift=-256)
+    group("config5 int16 2^28 (9-bit noise + 0.5% full range)", x, np.int16)
+    del x
+    x = devgen.outlier_mix(size(27), torch.int64, 6, device, body_bits=20, out_bits=50, shift=1 << 40).view(torch.uint64)
+    group("config5 uint64 2^27 (20 bits above 2^40 + 1% 50-bit outliers)", x, np.uint64)
+    del x
+
+    # configuration 4: int64, 2^30 values, eight block shapes in turn
+    x = devgen.block_mix_int64(size(30), 4, device)
+    group("config4 int64 2^30 (eight block shapes in turn)", x, np.int64)
+    del x
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,10 +400,20 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="leave out the other BASELINE configurations (the default one-GPU run times them too)")
+    ap.add_argument("--other-shrink", type=int, default=0,
+                    help="the other configurations at 2^-K of their sizes (tests of this script)")
+    ap.add_argument("--cpu-native-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl is RCCL)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0")
     args = ap.parse_args()
+
+    if args.cpu_native_child:
+        # the CPU baseline with whatever OROCH_REF_LIBRARY names; no GPU is touched
+        print(json.dumps(cpu_baseline(args.cpu_log2n, 3, args.config, native_child=True)))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -229,6 +435,10 @@ def main():
 
     if args.one_device:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        # one rank per GPU: ranks that shared a card would time each other
+        raise SystemExit("%d ranks but %d GPUs: start one rank per GPU (or pass --one-device to rehearse "
+                         "on one card)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     rc = oroch_amd.lib.oroch_hip_init(local_rank)
@@ -300,6 +510,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = oroch_amd.profile_stop()
+    mine = {"rank": rank, "device": local_rank,
+            "uuid": str(getattr(torch.cuda.get_device_properties(local_rank), "uuid", "")),
+            "name": torch.cuda.get_device_name(local_rank), "values": n, "ms_per_step": elapsed / args.steps * 1e3}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
     elapsed = sharding.max_over_ranks(elapsed, device)
     # per-phase device time of the last step (events are reused, so only the last survives)
     enc_ms = ev[0].elapsed_time(ev[1])
@@ -341,7 +558,7 @@ def main():
         for d, p in paths.items():
             p["achieved"] = p["algorithmic_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] else 0.0
             p["frac"] = p["achieved"] / HBM_PEAK_GBS
-            p["traffic"], p["traffic_commit"] = (measured_traffic(d, args.log2n) if args.config == "headline"
+            p["traffic"], p["traffic_record"] = (measured_traffic(d, args.log2n) if args.config == "headline"
                                                  and n == 1 << 30 else (None, None))
         # the figure of merit is the slower direction
         worse = min(paths, key=lambda d: paths[d]["frac"])
@@ -369,11 +586,17 @@ def main():
                          "achieved": paths[worse]["achieved"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": paths[worse]["frac"],
                          "traffic": paths[worse]["traffic"],
-                         "traffic_commit": paths[worse]["traffic_commit"],
+                         "traffic_record": paths[worse]["traffic_record"],
                          "algorithmic_bytes_per_launch": paths[worse]["algorithmic_bytes"],
                          "encode_path": paths["encode"], "decode_path": paths["decode"]},
             "shard_bytes": counts,
+            "ranks": ranks,
+            "built_with": oroch_amd.lib.oroch_hip_build_info().decode(),
         }
+        if world == 1 and args.config == "headline" and not args.no_other_configs:
+            del x, back, enc
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(device, shrink=args.other_shrink)
         if e2e is not None:
             line["end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:

@@ -3,11 +3,18 @@
 // varint appears as a cost model, as the coder of metadata scalars and of
 // exception lists, and as the varint / varfor block encodings; all of those
 // run inside the HIP kernels.  What this header keeps on the host is the
-// scalar form (a handful of bytes of metadata) and, for interface parity, the
-// sequence form written as a loop over it.
+// scalar form (a handful of bytes of metadata).  The sequence form
+// (varint.h:124-147, the README's example) goes to the device from
+// hip::varint_device_threshold values on when the value codec is the default
+// one; shorter sequences, and other value codecs, are a loop over the scalar
+// form.
 // Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_VARINT_H_
 #define OROCH_VARINT_H_
+
+#include <iterator>
+#include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "integer_traits.h"
@@ -15,9 +22,45 @@
 
 namespace oroch {
 
+namespace hip {
+
+// Sequences of at least this many values are coded on the device (below it
+// the trip over PCIe costs more than the loop).
+constexpr size_t varint_device_threshold = size_t(1) << 16;
+
+// How many sequence calls took the device route (tests look at it).
+inline size_t &varint_device_calls()
+{
+	static size_t calls = 0;
+	return calls;
+}
+
+// The values of a range as one array: the range itself when it already is one.
+template <typename T>
+inline const T *contiguous(const T *src, const T *, std::vector<T> &)
+{
+	return src;
+}
+template <typename T>
+inline const T *contiguous(T *src, T *, std::vector<T> &)
+{
+	return src;
+}
+template <typename T, typename Iter>
+inline const T *contiguous(Iter src, Iter const end, std::vector<T> &keep)
+{
+	keep = gather<T>(src, end);
+	return keep.data();
+}
+
+} // namespace hip
+
 template <typename T, typename V = zigzag_codec<T>>
 class varint_codec
 {
+	// the device kernels apply the default value codec (zigzag for signed T)
+	static constexpr bool device_codec = std::is_same<V, zigzag_codec<T>>::value;
+
 public:
 	using original_t = T;
 	using unsigned_t = typename integer_traits<T>::unsigned_t;
@@ -62,20 +105,58 @@ public:
 	template <typename Iter>
 	static size_t space(Iter src, Iter const end, value_codec vcodec = value_codec())
 	{
+		const size_t n = size_t(std::distance(src, end));
+		if (device_codec && n >= hip::varint_device_threshold) {
+			std::vector<T> keep;
+			const T *values = hip::contiguous<T>(src, end, keep);
+			uint64_t bytes = 0;
+			hip::check(oroch_varint_space_host(hip::dtype_of<T>(), values, n, &bytes), "varint space");
+			hip::varint_device_calls()++;
+			return size_t(bytes);
+		}
 		size_t count = 0;
 		while (src != end)
 			count += value_space(*src++, vcodec);
 		return count;
 	}
+	// (as in the reference, dst has room for what space() says)
 	template <typename Iter>
 	static void encode(dst_bytes_t &dst, Iter src, Iter const end, value_codec vcodec = value_codec())
 	{
+		const size_t n = size_t(std::distance(src, end));
+		if (device_codec && n >= hip::varint_device_threshold) {
+			std::vector<T> keep;
+			const T *values = hip::contiguous<T>(src, end, keep);
+			uint64_t bytes = 0;
+			hip::check(oroch_varint_encode_host(hip::dtype_of<T>(), values, n, dst, ~size_t(0), &bytes),
+				   "varint encode");
+			hip::varint_device_calls()++;
+			dst += bytes;
+			return;
+		}
 		while (src != end)
 			value_encode(dst, *src++, vcodec);
 	}
 	template <typename Iter>
 	static void decode(Iter dst, Iter const end, src_bytes_t &src, value_codec vcodec = value_codec())
 	{
+		const size_t n = size_t(std::distance(dst, end));
+		if (device_codec && n >= hip::varint_device_threshold) {
+			// The bytes of n values end with the n-th byte that has its top bit
+			// clear; only they are the caller's to read.
+			size_t nbytes = 0;
+			for (size_t left = n; left; nbytes++)
+				left -= (src[nbytes] & 0x80) == 0;
+			std::vector<T> values(n);
+			uint64_t used = 0;
+			hip::check(oroch_varint_decode_host(hip::dtype_of<T>(), src, nbytes, n, values.data(), &used),
+				   "varint decode");
+			hip::varint_device_calls()++;
+			for (size_t i = 0; i < n; i++)
+				*dst++ = values[i];
+			src += used;
+			return;
+		}
 		while (dst != end)
 			value_decode(*dst++, src, vcodec);
 	}

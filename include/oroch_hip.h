@@ -91,6 +91,9 @@ typedef struct oroch_block_stats {
 int oroch_hip_init(int device);
 /* Human-readable text for a return code of this library. */
 const char *oroch_hip_strerror(int code);
+/* The compiler and HIP version this library was built with (no counterpart in
+ * the reference; benchmarks record it beside their figures). */
+const char *oroch_hip_build_info(void);
 
 /* ---- sizes (host arithmetic) --------------------------------------------- */
 
@@ -177,6 +180,20 @@ int oroch_varint_encode(int dtype, const void *src, size_t n, void *dst, size_t 
 			void *workspace, size_t workspace_bytes, uint64_t *total_host, void *stream);
 int oroch_varint_decode(int dtype, const void *src, size_t nbytes, size_t n, void *dst,
 			void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The same three for values and bytes in host memory (varint.h:124-147 as the
+ * README's example calls them): staged to the device and back; they allocate
+ * and wait.  encode writes at most dst_capacity bytes (OROCH_E_CAPACITY if the
+ * code is longer; the caller sized dst from space); decode takes the nbytes at
+ * src_host, which must hold n complete values (OROCH_E_ARGUMENT otherwise),
+ * and reports how many of them the n values occupy.
+ */
+int oroch_varint_space_host(int dtype, const void *src_host, size_t n, uint64_t *space_host);
+int oroch_varint_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
+			     size_t dst_capacity, uint64_t *total_host);
+int oroch_varint_decode_host(int dtype, const void *src_host, size_t nbytes, size_t n, void *dst_host,
+			     uint64_t *consumed_host);
 
 /* ---- per-block statistics, selection, batch encode / decode --------------- */
 
@@ -570,9 +587,8 @@ int oroch_hip_profile_stop(double *ms, unsigned *launches);
  * returns the previous value, or OROCH_E_ARGUMENT for an unknown switch.
  */
 enum {
-	OROCH_OPT_ENCODE_PATH = 0,       /* 0 default; 1 select, scan, encode as separate launches;
-					    2 one block per wavefront in a single launch;
-					    3 four blocks per wavefront in a single launch */
+	OROCH_OPT_ENCODE_PATH = 0,       /* kept for callers that set it: the encoder has one path
+					    (select, scan, encode as separate launches) */
 	OROCH_OPT_SELECT_ONE_BLOCK = 1,  /* 1: one block per wavefront for every element type */
 	OROCH_OPT_ENCODE_ONE_BLOCK = 2,
 	OROCH_OPT_DECODE_ONE_BLOCK = 3,

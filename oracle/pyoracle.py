@@ -87,6 +87,7 @@ class Lib:
         else:
             f("group_decode", sz, [C.c_int, vp, sz, sz, vp])
             f("bench_blocks", None, [C.c_int, vp, sz, sz, C.c_int, vp])
+            f("bench_whole", None, [C.c_int, vp, sz, C.c_int, u64, u32, vp])
             f("array_script", sz, [C.c_int, vp, sz, vp, vp, sz, vp, vp, sz, vp, vp, sz])
 
     def _f(self, name, restype, argtypes):
@@ -236,6 +237,19 @@ class Lib:
         return out
 
 
+def _bench_whole(self, a, kind, origin, nbits):
+    """Reference only: seconds to (encode, decode) the whole sequence with the
+    caller's parameters (kind 0 bitpck, 1 bitfor, 2 bitpfr), and whether the
+    values came back."""
+    a = np.ascontiguousarray(a)
+    out = np.zeros(3, np.float64)
+    self._bench_whole(dtype_code(a.dtype), _ptr(a), a.size, kind, raw64(origin, a.dtype), nbits, _ptr(out))
+    return out
+
+
+Lib.bench_whole = _bench_whole
+
+
 def ref_array_script(values, ins_pos, ins_val, needles):
     """The reference's integer_array: insert values one by one at the end, then
     ins_val[k] at ins_pos[k], then find() every needle.  Returns (positions as
@@ -266,4 +280,4 @@ def _load(path, prefix):
 
 
 oracle = _load(os.path.join(HERE, "liboroch_oracle.so"), "orc_")
-ref = _load(os.path.join(HERE, "_ref", "liboroch_ref.so"), "ref_")
+ref = _load(os.path.join(HERE, os.environ.get("OROCH_REF_LIBRARY", os.path.join("_ref", "liboroch_ref.so"))), "ref_")

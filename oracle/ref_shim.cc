@@ -244,6 +244,45 @@ struct ref
 	// of its own).  Returns seconds per phase in out[0..2] = select, encode
 	// (metadata + data, given the selection), decode.
 	//
+	// Wall time of the whole-sequence codecs with the caller's parameters on
+	// one thread (the loop shape of tests/bench/group-bench.cc: buffers made
+	// once, then the calls timed): kind 0 bitpck, 1 bitfor, 2 bitpfr.
+	// out[0] = seconds to encode, out[1] = seconds to decode, out[2] = 1 when the
+	// values came back.
+	static void bench_whole(const T *src, size_t n, int kind, T origin, unsigned nbits, double *out)
+	{
+		std::vector<uint8_t> bytes(oroch::bitpck_codec<T>::space(n, nbits) + 16);
+		std::vector<T> back(n);
+		typename oroch::bitpfr_codec<T>::exceptions x;
+		auto now = [] { return std::chrono::steady_clock::now(); };
+		auto t0 = now();
+		oroch::dst_bytes_t d = bytes.data();
+		if (kind == 0) {
+			oroch::bitpck_codec<T>::encode(d, src, src + n, nbits);
+		} else if (kind == 1) {
+			typename oroch::bitfor_codec<T>::parameters p(origin, nbits);
+			oroch::bitfor_codec<T>::encode(d, src, src + n, p);
+		} else {
+			typename oroch::bitpfr_codec<T>::parameters p(origin, nbits, x);
+			oroch::bitpfr_codec<T>::encode(d, src, src + n, p);
+		}
+		auto t1 = now();
+		oroch::src_bytes_t s = bytes.data();
+		if (kind == 0) {
+			oroch::bitpck_codec<T>::decode(back.begin(), back.end(), s, nbits);
+		} else if (kind == 1) {
+			typename oroch::bitfor_codec<T>::parameters p(origin, nbits);
+			oroch::bitfor_codec<T>::decode(back.begin(), back.end(), s, p);
+		} else {
+			typename oroch::bitpfr_codec<T>::parameters p(origin, nbits, x);
+			oroch::bitpfr_codec<T>::decode(back.begin(), back.end(), s, p);
+		}
+		auto t2 = now();
+		out[0] = std::chrono::duration<double>(t1 - t0).count();
+		out[1] = std::chrono::duration<double>(t2 - t1).count();
+		out[2] = std::equal(back.begin(), back.end(), src) ? 1.0 : 0.0;
+	}
+
 	static void bench_blocks(const T *src, size_t n, size_t block, int threads, double *out)
 	{
 		size_t nblocks = n / block;
@@ -433,6 +472,10 @@ size_t ref_array_script(int dtype, const void *values, size_t n, const uint64_t 
 {
 	DISPATCH(dtype, array_script<T>((const T *) values, n, ins_pos, (const T *) ins_val, nops, taken,
 					(const T *) needles, m, found, info, info_capacity));
+}
+void ref_bench_whole(int dtype, const void *src, size_t n, int kind, uint64_t origin, unsigned nbits, double *out)
+{
+	DISPATCH(dtype, ref<T>::bench_whole((const T *) src, n, kind, T(origin), nbits, out));
 }
 void ref_bench_blocks(int dtype, const void *src, size_t n, size_t block, int threads, double *out)
 {

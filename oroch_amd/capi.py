@@ -54,6 +54,7 @@ def _load():
     sig = {
         "oroch_hip_init": (i, [i]),
         "oroch_hip_strerror": (C.c_char_p, [i]),
+        "oroch_hip_build_info": (C.c_char_p, []),
         "oroch_bitpck_capacity": (sz, [u32]),
         "oroch_bitpck_space": (sz, [sz, u32]),
         "oroch_bitpck_encode": (i, [i, vp, sz, u32, vp, vp]),
@@ -68,6 +69,9 @@ def _load():
         "oroch_varint_space": (i, [i, vp, sz, vp, sz, vp, vp]),
         "oroch_varint_encode": (i, [i, vp, sz, vp, sz, vp, sz, vp, vp]),
         "oroch_varint_decode": (i, [i, vp, sz, sz, vp, vp, sz, vp]),
+        "oroch_varint_space_host": (i, [i, vp, sz, vp]),
+        "oroch_varint_encode_host": (i, [i, vp, sz, vp, sz, vp]),
+        "oroch_varint_decode_host": (i, [i, vp, sz, sz, vp, vp]),
         "oroch_bitpfr_patch": (i, [i, vp, sz, u64, u32, vp, vp, sz, vp, sz, vp]),
         "oroch_group_select": (i, [i, vp, sz, vp, vp]),
         "oroch_group_bound": (sz, [i, sz]),

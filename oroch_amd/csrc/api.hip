@@ -125,12 +125,7 @@ struct option_table
 			const char *e = getenv(name);
 			return e && *e ? atoi(e) : 0;
 		};
-		int path = env("OROCH_HIP_ENCODE_PATH");
-		if (env("OROCH_HIP_TWO_PASS"))
-			path = 1;
-		else if (env("OROCH_HIP_SINGLE_PASS"))
-			path = 2;
-		v[OROCH_OPT_ENCODE_PATH] = path;
+		v[OROCH_OPT_ENCODE_PATH] = env("OROCH_HIP_ENCODE_PATH");
 		v[OROCH_OPT_SELECT_ONE_BLOCK] = env("OROCH_HIP_SELECT_ONE_BLOCK");
 		v[OROCH_OPT_ENCODE_ONE_BLOCK] = env("OROCH_HIP_ENCODE_ONE_BLOCK");
 		v[OROCH_OPT_DECODE_ONE_BLOCK] = env("OROCH_HIP_DECODE_ONE_BLOCK");
@@ -184,6 +179,14 @@ extern "C" int oroch_hip_init(int device)
 		return OROCH_E_NOGPU;
 	// this device's copy of the scratch array of the non-allocating entry point
 	return oroch_hip::static_scratch_setup(nullptr);
+}
+
+#define OROCH_STR2(x) #x
+#define OROCH_STR(x) OROCH_STR2(x)
+extern "C" const char *oroch_hip_build_info(void)
+{
+	return "hipcc (HIP " OROCH_STR(HIP_VERSION_MAJOR) "." OROCH_STR(HIP_VERSION_MINOR) "." OROCH_STR(HIP_VERSION_PATCH)
+	       ", clang " __clang_version__ "), --offload-arch=gfx950 -O3";
 }
 
 extern "C" const char *oroch_hip_strerror(int code)

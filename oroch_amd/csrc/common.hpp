@@ -378,45 +378,6 @@ __device__ __forceinline__ void load16(const typename E::S *p, typename E::C (&v
 	}
 }
 
-// Thirty-two consecutive elements at p (4-byte aligned) as raw W-bit patterns.
-template <typename E>
-__device__ __forceinline__ void load32(const typename E::S *p, typename E::C (&v)[32])
-{
-	const uint4 *q = reinterpret_cast<const uint4 *>(p);
-	static_assert(E::BYTES <= 4, "element types up to 32 bits");
-	if constexpr (E::BYTES == 4) {
-#pragma unroll
-		for (int k = 0; k < 8; k++) {
-			const uint4 a = q[k];
-			v[4 * k] = a.x, v[4 * k + 1] = a.y, v[4 * k + 2] = a.z, v[4 * k + 3] = a.w;
-		}
-	} else if constexpr (E::BYTES == 2) {
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const uint4 a = q[k];
-			const uint32_t d[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				v[8 * k + 2 * i] = d[i] & 0xffffu;
-				v[8 * k + 2 * i + 1] = d[i] >> 16;
-			}
-		}
-	} else {
-#pragma unroll
-		for (int k = 0; k < 2; k++) {
-			const uint4 a = q[k];
-			const uint32_t d[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				v[16 * k + 4 * i] = d[i] & 0xffu;
-				v[16 * k + 4 * i + 1] = (d[i] >> 8) & 0xffu;
-				v[16 * k + 4 * i + 2] = (d[i] >> 16) & 0xffu;
-				v[16 * k + 4 * i + 3] = d[i] >> 24;
-			}
-		}
-	}
-}
-
 // ---- bit-granular access to a byte image held in LDS -----------------------
 //
 // `img` is a 4-byte aligned LDS array; `bit` an absolute bit position in it.

@@ -19,7 +19,6 @@
 #include "common.hpp"
 #include "bitfield.hpp"
 #include "scan.hpp"
-#include "chain.hpp"
 #include "block.hpp"
 
 // Most workgroups a launch of each block kernel asks for (grid_for).  Found by
@@ -31,9 +30,6 @@
 // the selection want longer walks than the encoders.
 #ifndef GRID_SELECT_QUAD
 #define GRID_SELECT_QUAD 16384u
-#endif
-#ifndef GRID_SELECT_OCTO
-#define GRID_SELECT_OCTO 16384u
 #endif
 #ifndef GRID_ENCODE_QUAD
 #define GRID_ENCODE_QUAD 65536u
@@ -847,144 +843,6 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode(const typename E:
 	}
 }
 
-// ---- single-pass encode ----------------------------------------------------------------
-//
-// Selection, image building and the offsets scan in ONE launch, so the values
-// are read from HBM once.  A tile is FUSED_WAVES * R consecutive blocks owned by
-// one workgroup: every wavefront selects and builds the images of its R blocks
-// back to back in an LDS arena (that arena already is the wave's piece of the
-// stream), the workgroup publishes its byte count, looks back over the counts
-// of the tiles before it (chained scan with decoupled look-back) and copies
-// the arenas out at the resulting offset.
-//
-// Workgroups are persistent: workgroup g handles tiles g, g + G, g + 2G, ...
-// and a tile only ever waits for lower-numbered tiles.  The grid is sized to
-// what the chip holds at once, so the owner of the lowest unfinished tile is
-// always running and the chain cannot stall.  Every wait is bounded all the
-// same: if one runs out, the abort word is set, nothing more is written and
-// the host falls back to the two-pass path.
-//
-// state[t]: bits 63..62 = 0 nothing yet, 1 = bytes of tile t, 2 = bytes of
-// tiles 0..t; bits 61..0 the byte count.  One naturally aligned 8-byte word
-// written by one write-through store and polled with cache-bypassing loads, so
-// it needs no fence.
-
-constexpr int FUSED_WAVES = 4;
-template <typename E>
-constexpr int fused_blocks_per_wave()
-{
-	return E::BYTES == 8 ? 2 : 4;
-}
-
-template <typename E>
-__global__ __launch_bounds__(WAVE *FUSED_WAVES) void k_encode_fused(
-	const typename E::S *src, size_t n, size_t nblocks, size_t ntiles, uint8_t *dst,
-	uint64_t *offsets, uint64_t *state, uint32_t *abort_flag)
-{
-	constexpr int R = fused_blocks_per_wave<E>();
-	constexpr int IMG = image_bytes<E>() - 16; // longest image, rounded up to 16
-	constexpr int ARENA = R * IMG + 16;
-	__shared__ __attribute__((aligned(16))) uint32_t arena[FUSED_WAVES][ARENA / 4];
-	__shared__ __attribute__((aligned(16))) uint32_t hist2[FUSED_WAVES][264];
-	__shared__ uint4 wt[65];
-	__shared__ uint32_t blkpos[FUSED_WAVES][R];
-	__shared__ uint32_t wave_total[FUSED_WAVES];
-	__shared__ uint64_t tile_base;
-	__shared__ uint32_t aborted;
-	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
-	load_width_table(wt);
-	const lane_consts lc = make_lane_consts(wt, lane);
-
-	// The wave's blocks in the order it meets them: tile blockIdx.x + (j / R) *
-	// gridDim.x, block j % R of the wave's share.  Loads run two blocks ahead of
-	// the block being worked on, so that every wave keeps a few KiB in flight
-	// (HBM latency is several thousand cycles under load).
-	auto block_of = [&](size_t j) -> size_t {
-		const size_t tile = blockIdx.x + (j / R) * gridDim.x;
-		return tile < ntiles ? (tile * FUSED_WAVES + wave) * R + j % R : nblocks;
-	};
-	auto count_of = [&](size_t blk) -> int {
-		return blk < nblocks ? block_count(n, blk) : 0;
-	};
-	typename E::C v[VPL], v1[VPL], v2[VPL];
-	size_t j = 0;
-	load_block<E>(src, block_of(0) * BLOCK, count_of(block_of(0)), lane, v);
-	load_block<E>(src, block_of(1) * BLOCK, count_of(block_of(1)), lane, v1);
-
-	for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		const size_t blk0 = (tile * FUSED_WAVES + wave) * R;
-		uint32_t pos = 0;
-#pragma unroll 1
-		for (int r = 0; r < R; r++, j++) {
-			const size_t blk = blk0 + r;
-			if (lane == 0)
-				blkpos[wave][r] = pos;
-			{
-				const size_t ahead = block_of(j + 2);
-				load_block<E>(src, ahead * BLOCK, count_of(ahead), lane, v2);
-			}
-			if (blk < nblocks) {
-				const int nv = count_of(blk);
-				selection<typename E::C> sel;
-				uint32_t len;
-				select_any<E>(v, nv, lane, hist2[wave], wt, lc, sel);
-				if (nv == BLOCK)
-					len = encode_block<E, true>(v, nv, lane, sel, wt, arena[wave] + pos / 4);
-				else
-					len = encode_block<E, false>(v, nv, lane, sel, wt, arena[wave] + pos / 4);
-				pos += (len + 15u) & ~15u;
-			}
-#pragma unroll
-			for (int s = 0; s < VPL; s++) {
-				v[s] = v1[s];
-				v1[s] = v2[s];
-			}
-		}
-		if (lane == 0)
-			wave_total[wave] = pos;
-		__syncthreads();
-		if (wave == 0) {
-			uint32_t tile_bytes = 0;
-#pragma unroll
-			for (int w = 0; w < FUSED_WAVES; w++)
-				tile_bytes += wave_total[w];
-			if (lane == 0)
-				state_store(&state[tile], (tile == 0 ? ST_PREFIX : ST_AGG) | tile_bytes);
-			uint64_t exclusive = 0;
-			const bool ok = tile == 0 || look_back(state, tile, lane, abort_flag, exclusive);
-			if (lane == 0) {
-				if (ok && tile != 0)
-					state_store(&state[tile], ST_PREFIX | (exclusive + tile_bytes));
-				if (!ok)
-					__hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (ok && tile == ntiles - 1)
-					offsets[nblocks] = exclusive + tile_bytes;
-				tile_base = exclusive;
-				aborted = ok ? 0u : 1u;
-			}
-		}
-		__syncthreads();
-		if (!aborted) {
-			uint64_t base = tile_base;
-			for (int w = 0; w < wave; w++)
-				base += wave_total[w];
-			const uint8_t *a8 = reinterpret_cast<const uint8_t *>(arena[wave]);
-			for (uint32_t o = uint32_t(lane) * 16u; o < pos; o += WAVE * 16u)
-				*reinterpret_cast<uint4 *>(dst + base + o) = *reinterpret_cast<const uint4 *>(a8 + o);
-			if (lane < R && blk0 + lane < nblocks)
-				offsets[blk0 + lane] = base + blkpos[wave][lane];
-		}
-		__syncthreads();
-	}
-}
-
-// offsets[nblocks] = all ones when the single-pass kernel gave up.
-__global__ void k_fused_finish(const uint32_t *abort_flag, uint64_t *offsets, size_t nblocks)
-{
-	if (*abort_flag)
-		offsets[nblocks] = ~uint64_t(0);
-}
-
 // ---- block statistics --------------------------------------------------------------
 //
 // integer_stats.h:48-53 (count, min, max) and :74-80, 97-102 (histogram of the
@@ -1059,8 +917,6 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) DECODE_BLOCK_ATTR void k_decode
 #include "decode_quad.hpp"
 #include "encode_quad.hpp"
 #include "select_quad.hpp"
-#include "fused_quad.hpp"
-#include "octo.hpp"
 
 namespace oroch_hip {
 
@@ -1082,17 +938,6 @@ struct group_ws
 	uint32_t *sizes;
 	uint64_t *tile_sums;
 	uint64_t *total;
-	uint32_t *abort_flag;  // 16 bytes, directly in front of state (one memset)
-	uint64_t *state;       // one word per tile of the single-pass kernel
-	size_t state_bytes;    // abort word + state, a multiple of 16
-	// the four-blocks-per-wavefront single launch: abort word, A, S, P (one memset)
-	uint32_t *fq_abort;
-	fq_state fq;
-	size_t fq_bytes, fq_rows;
-	// eight blocks per wavefront, single launch: abort word and table (one memset)
-	uint32_t *oc_abort;
-	oc_state oc;
-	size_t oc_bytes, oc_rows;
 	size_t bytes;
 };
 
@@ -1111,75 +956,13 @@ static group_ws carve_ws(void *ws, size_t n)
 	off = align_up(off + (ntiles + 1) * sizeof(uint64_t), 256);
 	w.total = reinterpret_cast<uint64_t *>(p + off);
 	off = align_up(off + 256, 256);
-	// the smallest tile is FUSED_WAVES * 2 blocks
-	const size_t max_tiles = (nb + FUSED_WAVES * 2 - 1) / (FUSED_WAVES * 2);
-	w.abort_flag = reinterpret_cast<uint32_t *>(p + off);
-	w.state = reinterpret_cast<uint64_t *>(p + off + 16);
-	w.state_bytes = align_up(16 + max_tiles * sizeof(uint64_t), 16);
-	off = align_up(off + w.state_bytes, 256);
-	{
-		// a row per round of the single launch's table, for the fewest workgroups
-		// it may run with (one)
-		const size_t ntiles = (nb + QUAD - 1) / QUAD;
-		// (the launch takes one workgroup per CU; a device with fewer than 64 CUs
-		// falls back to the separate launches for arrays this does not cover)
-		const size_t max_rounds = ntiles / (size_t(FQ_WORKERS) * 64) + 2;
-		w.fq_abort = reinterpret_cast<uint32_t *>(p + off);
-		w.fq.abort_flag = w.fq_abort;
-		w.fq.rows = reinterpret_cast<uint16_t *>(p + off + 128);
-		w.fq.dbg = nullptr;
-		w.fq_rows = max_rounds;
-		w.fq_bytes = 128 + max_rounds * FQ_MAX_GROUPS * sizeof(uint16_t);
-		off = align_up(off + w.fq_bytes, 256);
-	}
-	{
-		// the same table for the launch of eight blocks per wavefront
-		const size_t ntiles = (nb + OCT - 1) / OCT;
-		const size_t max_rounds = ntiles / (size_t(OC_WORKERS) * 64) + 2;
-		w.oc_abort = reinterpret_cast<uint32_t *>(p + off);
-		w.oc.abort_flag = w.oc_abort;
-		w.oc.rows = reinterpret_cast<uint16_t *>(p + off + 128);
-		w.oc_rows = max_rounds;
-		w.oc_bytes = 128 + max_rounds * OC_MAX_GROUPS * sizeof(uint16_t);
-		off = align_up(off + w.oc_bytes, 256);
-	}
 	w.bytes = off;
 	return w;
 }
 
-// Workgroups of the single-pass kernel the device holds at once.  The occupancy
-// query can read one workgroup per CU high for kernels with many scalar
-// registers, and a grid that is not fully resident would stall the look-back
-// chain, so one workgroup per CU is given up as margin.
-template <typename E>
-static int fused_resident_workgroups()
-{
-	static int cached = 0;
-	if (cached)
-		return cached;
-	int dev = 0, cus = 0, per_cu = 0;
-	if (hipGetDevice(&dev) != hipSuccess ||
-	    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_encode_fused<E>, WAVE * FUSED_WAVES,
-							  0) != hipSuccess)
-		return -1;
-	per_cu = per_cu > 8 ? 8 : per_cu;
-	// the query is exact when vector registers or LDS are the limit; it can be
-	// one high only where the scalar-register file is (7 or 8 per CU)
-	if (per_cu >= 7)
-		per_cu -= 1;
-	if (per_cu < 1 || cus < 1)
-		return -1;
-	cached = per_cu * cus;
-	return cached;
-}
-
-// Which encode path runs (OROCH_OPT_ENCODE_PATH): the single-pass kernel reads
-// the values once but currently loses more to its lower occupancy and the
-// look-back waits than it saves, so the two-pass path (select, scan, encode) is
-// the default.  The *_ONE_BLOCK switches keep the one-block-per-wavefront
-// kernels for every element type (the 64-bit types always use them), so that
-// tests can compare the two.
+// The *_ONE_BLOCK switches keep the one-block-per-wavefront kernels for every
+// element type (the 64-bit types always use them), so that tests can compare
+// the two.
 static bool one_block_decode_forced()
 {
 	return option(OROCH_OPT_DECODE_ONE_BLOCK) != 0;
@@ -1215,22 +998,7 @@ static int launch_select(const void *src, size_t n, size_t nb, oroch_block_desc 
 			 hipStream_t st)
 {
 	if constexpr (sizeof(typename E::C) == 4) {
-		if (option(OROCH_OPT_SELECT_ONE_BLOCK) == 2 && n / (size_t(OCT) * BLOCK) > 0) {
-			// eight blocks per wavefront for the full octets, the rest one by one
-			const size_t noct = n / (size_t(OCT) * BLOCK);
-			hipLaunchKernelGGL(k_select_octo<E>, dim3(grid_for(noct, GRID_SELECT_OCTO)),
-					   dim3(WAVE * WAVES_PER_WG), 0, st, static_cast<const typename E::S *>(src),
-					   noct, desc, sizes);
-			const size_t done = noct * OCT;
-			if (done < nb)
-				hipLaunchKernelGGL(k_select<E>, dim3(grid_for(nb - done, GRID_SELECT)),
-						   dim3(WAVE * WAVES_PER_WG), 0, st,
-						   static_cast<const typename E::S *>(src) + done * BLOCK,
-						   n - done * BLOCK, nb - done, desc ? desc + done : nullptr,
-						   sizes ? sizes + done : nullptr);
-			return int(hipGetLastError());
-		}
-		if (option(OROCH_OPT_SELECT_ONE_BLOCK) != 1) {
+		if (!option(OROCH_OPT_SELECT_ONE_BLOCK)) {
 			const size_t nq = (nb + QUAD - 1) / QUAD;
 			const unsigned qgrid = grid_for(nq, GRID_SELECT_QUAD);
 			hipLaunchKernelGGL(k_select_quad<E>, dim3(qgrid), dim3(WAVE * WAVES_PER_WG), 0, st,
@@ -1334,8 +1102,14 @@ static int group_encode_impl(int dtype, const void *src, size_t n, void *dst, si
 		return rc;
 	}
 	group_ws w = carve_ws(workspace, n);
-	auto two_pass = [&]() {
-		return dispatch_dtype(dtype, [&](auto e) {
+	// select -> scan -> encode as separate launches.  (Kernels that did all three
+	// in one launch and read the values once were built and measured over two
+	// rounds -- one, four and eight blocks per wavefront, offsets exchanged
+	// through chained scans or a table of rows -- and every one of them was
+	// slower than this: the exchange is a barrier across the chip per round of
+	// tiles, and what hides it, LDS for several finished tiles per wavefront,
+	// costs the occupancy the instruction streams need.)
+	rc = dispatch_dtype(dtype, [&](auto e) {
 			using E = decltype(e);
 			int r;
 			{
@@ -1366,143 +1140,7 @@ static int group_encode_impl(int dtype, const void *src, size_t n, void *dst, si
 					   static_cast<const typename E::S *>(src), n, nb, w.desc, offsets,
 					   static_cast<uint8_t *>(dst));
 			return int(hipGetLastError());
-		});
-	};
-	auto single_pass = [&]() {
-		return dispatch_dtype(dtype, [&](auto e) {
-			using E = decltype(e);
-			constexpr int per_tile = FUSED_WAVES * fused_blocks_per_wave<E>();
-			const size_t ntiles = (nb + per_tile - 1) / per_tile;
-			const int resident = fused_resident_workgroups<E>();
-			if (resident <= 0)
-				return int(hipErrorInvalidValue);
-			const unsigned grid = unsigned(ntiles < size_t(resident) ? ntiles : size_t(resident));
-			int r = int(hipMemsetAsync(w.abort_flag, 0, w.state_bytes, st));
-			if (r)
-				return r;
-			{
-				profile_scope ps(OROCH_K_ENCODE, st);
-				hipLaunchKernelGGL(k_encode_fused<E>, dim3(grid), dim3(WAVE * FUSED_WAVES), 0, st,
-						   static_cast<const typename E::S *>(src), n, nb, ntiles,
-						   static_cast<uint8_t *>(dst), offsets, w.state, w.abort_flag);
-				r = int(hipGetLastError());
-			}
-			if (r)
-				return r;
-			hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, st, w.abort_flag, offsets, nb);
-			return int(hipGetLastError());
-		});
-	};
-	auto fused_quad = [&]() {
-		return dispatch_dtype(dtype, [&](auto e) {
-			using E = decltype(e);
-			if constexpr (sizeof(typename E::C) == 4) {
-				const size_t ntiles = (nb + QUAD - 1) / QUAD;
-				const int resident = fq_resident_workgroups<E>();
-				if (resident <= 0)
-					return int(hipErrorInvalidValue);
-				const size_t want = (ntiles + FQ_WORKERS - 1) / FQ_WORKERS;
-				const unsigned grid = unsigned(want < size_t(resident) ? want : size_t(resident));
-				const size_t per_round = size_t(grid) * FQ_WORKERS;
-				if ((ntiles + per_round - 1) / per_round > w.fq_rows)
-					return two_pass();
-				int r = int(hipMemsetAsync(w.fq_abort, 0, w.fq_bytes, st));
-				if (r)
-					return r;
-				{
-					profile_scope ps(OROCH_K_ENCODE, st);
-					hipLaunchKernelGGL(k_fused_quad<E>, dim3(grid), dim3(FQ_THREADS), 0, st,
-							   static_cast<const typename E::S *>(src), n, nb, ntiles,
-							   static_cast<uint8_t *>(dst), offsets, w.fq);
-					r = int(hipGetLastError());
-				}
-				if (r)
-					return r;
-#ifdef FQ_STATS
-				{
-					unsigned long long h[32];
-					(void) hipDeviceSynchronize();
-					(void) hipMemcpyFromSymbol(h, HIP_SYMBOL(fq_stats), sizeof h);
-					fprintf(stderr, "fq tiles %zu, grid %u: exchanger polls %llu (ok %llu, not yet %llu; %llu cycles for the loads); workers per tile in cycles: waited %llu (%llu waits), values %llu, select %llu, to publish %llu, to encode %llu, encode %llu, all %llu\n",
-						ntiles, grid, h[0], h[1], h[5], h[0] ? h[18] * 16 / h[0] : 0, h[10] * 16 / ntiles, h[4],
-						h[12] * 16 / ntiles, h[13] * 16 / ntiles, h[2] * 16 / ntiles, h[3] * 16 / ntiles, h[14] * 16 / ntiles, h[11] * 16 / ntiles);
-					unsigned long long z[32] = {0};
-					(void) hipMemcpyToSymbol(HIP_SYMBOL(fq_stats), z, sizeof z);
-				}
-#endif
-				hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, st, w.fq_abort, offsets, nb);
-				return int(hipGetLastError());
-			} else {
-				return single_pass();
-			}
-		});
-	};
-	auto fused_octo = [&]() {
-		return dispatch_dtype(dtype, [&](auto e) {
-			using E = decltype(e);
-			if constexpr (sizeof(typename E::C) == 4) {
-				const size_t ntiles = (nb + OCT - 1) / OCT;
-				const int resident = oc_resident_workgroups<E>();
-				// (tiles that are not whole read the first tile's values in passing)
-				if (resident <= 0 || n < size_t(OCT) * BLOCK)
-					return two_pass();
-				const size_t want = (ntiles + OC_WORKERS - 1) / OC_WORKERS;
-				const unsigned grid = unsigned(want < size_t(resident) ? want : size_t(resident));
-				const size_t per_round = size_t(grid) * OC_WORKERS;
-				if ((ntiles + per_round - 1) / per_round > w.oc_rows)
-					return two_pass();
-				int r = int(hipMemsetAsync(w.oc_abort, 0, w.oc_bytes, st));
-				if (r)
-					return r;
-				{
-					profile_scope ps(OROCH_K_ENCODE, st);
-					hipLaunchKernelGGL(k_fused_octo<E>, dim3(grid), dim3(OC_THREADS), 0, st,
-							   static_cast<const typename E::S *>(src), n, nb, ntiles,
-							   static_cast<uint8_t *>(dst), offsets, w.oc);
-					r = int(hipGetLastError());
-				}
-				if (r)
-					return r;
-#ifdef OC_STATS
-				{
-					unsigned long long h[16];
-					(void) hipDeviceSynchronize();
-					(void) hipMemcpyFromSymbol(h, HIP_SYMBOL(oc_stats), sizeof h);
-					const double t = double(h[8] ? h[8] : 1);
-					fprintf(stderr, "octo: %llu tiles, cycles per tile: wait for values %.0f, select %.0f, prepare %.0f, wait for writer %.0f, pack %.0f, all %.0f\n",
-						h[8], h[0] / t, h[1] / t, h[2] / t, h[3] / t, h[4] / t, h[5] / t);
-					unsigned long long z[16] = {0};
-					(void) hipMemcpyToSymbol(HIP_SYMBOL(oc_stats), z, sizeof z);
-				}
-#endif
-				hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, st, w.oc_abort, offsets, nb);
-				return int(hipGetLastError());
-			} else {
-				return two_pass();
-			}
-		});
-	};
-	const int path = option(OROCH_OPT_ENCODE_PATH);
-	// A single launch that gives up leaves ~0 as the stream length, which only a
-	// caller that reads the length back can notice and repair: the others
-	// (the entry point that allocates nothing, the host pipeline) always take
-	// the separate launches.
-	const bool force_two_pass = (path != 2 && path != 3 && path != 4) || !total_host;
-	rc = force_two_pass ? two_pass() : path == 4 ? fused_octo() : path == 3 ? fused_quad() : single_pass();
-	if (rc == 0 && total_host && !force_two_pass) {
-		// the only place the host can see that the single-pass kernel gave up
-		uint64_t total = 0;
-		rc = int(hipMemcpyAsync(&total, offsets + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-		if (rc == 0)
-			rc = int(hipStreamSynchronize(st));
-		if (rc)
-			return rc;
-		if (total != ~uint64_t(0)) {
-			*total_host = total;
-			return 0;
-		}
-		rc = two_pass();
-	}
+	});
 	if (rc == 0 && total_host) {
 		rc = int(hipMemcpyAsync(total_host, offsets + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
 		if (rc == 0)

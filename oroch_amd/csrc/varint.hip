@@ -10,6 +10,7 @@
 // byte walks back over the (at most nine) bytes before it.
 #include "common.hpp"
 #include "scan.hpp"
+#include "host_util.hpp"
 
 namespace oroch_hip {
 
@@ -379,4 +380,93 @@ extern "C" int oroch_varint_decode(int dtype, const void *src, size_t nbytes, si
 				   void *workspace, size_t workspace_bytes, void *stream)
 {
 	return varint_decode_counted(dtype, src, nbytes, n, dst, workspace, workspace_bytes, nullptr, stream);
+}
+
+// ---- host buffers ------------------------------------------------------------------
+//
+// The sequence calls of varint_codec<T> (varint.h:124-147) for values and bytes
+// in host memory: staged to the device, coded there, staged back.  They allocate
+// and wait; what they save is the CPU's loop over the values.
+
+extern "C" int oroch_varint_space_host(int dtype, const void *src_host, size_t n, uint64_t *space_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (!space_host || (n && !src_host))
+		return OROCH_E_ARGUMENT;
+	*space_host = 0;
+	if (n == 0)
+		return 0;
+	const size_t bytes = n << (dtype >> 1);
+	dev_buf in, ws;
+	int rc;
+	if ((rc = in.alloc(bytes)) || (rc = ws.alloc(oroch_varint_workspace(n))))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, bytes, true, nullptr)))
+		return rc;
+	return oroch_varint_space(dtype, in.p, n, ws.p, oroch_varint_workspace(n), space_host, nullptr);
+}
+
+extern "C" int oroch_varint_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
+					size_t dst_capacity, uint64_t *total_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n && (!src_host || !dst_host))
+		return OROCH_E_ARGUMENT;
+	if (total_host)
+		*total_host = 0;
+	if (n == 0)
+		return 0;
+	const size_t bytes = n << (dtype >> 1);
+	const size_t worst = n * size_t(((8u << (dtype >> 1)) + 6u) / 7u);
+	dev_buf in, out, ws;
+	int rc;
+	if ((rc = in.alloc(bytes)) || (rc = out.alloc(worst)) || (rc = ws.alloc(oroch_varint_workspace(n))))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, bytes, true, nullptr)))
+		return rc;
+	uint64_t total = 0;
+	if ((rc = oroch_varint_encode(dtype, in.p, n, out.p, worst, ws.p, oroch_varint_workspace(n), &total, nullptr)))
+		return rc;
+	if (total > dst_capacity)
+		return OROCH_E_CAPACITY;
+	if (total_host)
+		*total_host = total;
+	return staged_copy(dst_host, out.p, size_t(total), false, nullptr);
+}
+
+extern "C" int oroch_varint_decode_host(int dtype, const void *src_host, size_t nbytes, size_t n, void *dst_host,
+					uint64_t *consumed_host)
+{
+	if (dtype < 0 || dtype > 7)
+		return OROCH_E_DTYPE;
+	if (n && (!src_host || !dst_host || !nbytes))
+		return OROCH_E_ARGUMENT;
+	if (consumed_host)
+		*consumed_host = 0;
+	if (n == 0)
+		return 0;
+	const size_t bytes = n << (dtype >> 1);
+	dev_buf in, out, ws, used;
+	int rc;
+	if ((rc = in.alloc(nbytes)) || (rc = out.alloc(bytes)) || (rc = ws.alloc(oroch_varint_workspace(nbytes))) ||
+	    (rc = used.alloc(sizeof(uint64_t))))
+		return rc;
+	if ((rc = int(hipMemsetAsync(used.p, 0xff, sizeof(uint64_t), nullptr))))
+		return rc;
+	if ((rc = staged_copy(in.p, src_host, nbytes, true, nullptr)))
+		return rc;
+	if ((rc = varint_decode_counted(dtype, in.p, nbytes, n, out.p, ws.p, oroch_varint_workspace(nbytes),
+					static_cast<uint64_t *>(used.p), nullptr)))
+		return rc;
+	uint64_t consumed = 0;
+	if ((rc = int(hipMemcpy(&consumed, used.p, sizeof consumed, hipMemcpyDeviceToHost))))
+		return rc;
+	// (left alone by the kernel when the bytes hold fewer than n values)
+	if (consumed == ~uint64_t(0))
+		return OROCH_E_ARGUMENT;
+	if (consumed_host)
+		*consumed_host = consumed;
+	return staged_copy(dst_host, out.p, bytes, false, nullptr);
 }

@@ -655,9 +655,58 @@ static void test_errors()
 		REQUIRE(oroch::bitfor_codec<int32_t>::fetch(framed.data(), i, params) == q[i]);
 }
 
+// varint_codec<T>::space / encode / decode over a sequence (the README's
+// example, tests/unit/varint.cc:67-84 at scale): from the threshold on the
+// calls go to the device and give the bytes of the scalar loop.
+template <typename T>
+static void test_varint_sequences()
+{
+	using codec = oroch::varint_codec<T>;
+	const size_t n = oroch::hip::varint_device_threshold * 3 + 77;
+	std::vector<T> values(n);
+	for (size_t i = 0; i < n; i++) {
+		const uint64_t r = rnd();
+		// magnitudes of every length, both signs for signed T
+		values[i] = T(r >> (8 + (r & 63) % (8 * sizeof(T))));
+		if (std::numeric_limits<T>::is_signed && (r & 64))
+			values[i] = T(~values[i]);
+	}
+	std::vector<uint8_t> want;
+	for (size_t i = 0; i < n; i++) {
+		uint8_t tmp[16];
+		oroch::dst_bytes_t d = tmp;
+		codec::value_encode(d, values[i]);
+		want.insert(want.end(), tmp, d);
+	}
+	const size_t before = oroch::hip::varint_device_calls();
+	REQUIRE(codec::space(values.begin(), values.end()) == want.size());
+	std::vector<uint8_t> bytes(want.size() + 32, 0xee);
+	oroch::dst_bytes_t d = bytes.data();
+	codec::encode(d, values.data(), values.data() + n);
+	REQUIRE(size_t(d - bytes.data()) == want.size());
+	REQUIRE(std::equal(want.begin(), want.end(), bytes.begin()));
+	REQUIRE(bytes[want.size()] == 0xee);
+	std::vector<T> back(n);
+	oroch::src_bytes_t s = bytes.data();
+	codec::decode(back.begin(), back.end(), s);
+	REQUIRE(size_t(s - bytes.data()) == want.size());
+	REQUIRE(back == values);
+	REQUIRE(oroch::hip::varint_device_calls() == before + 3);
+	// below the threshold the loop runs on the host
+	const size_t few = 100;
+	REQUIRE(codec::space(values.begin(), values.begin() + few) > 0);
+	d = bytes.data();
+	codec::encode(d, values.begin(), values.begin() + few);
+	s = bytes.data();
+	codec::decode(back.begin(), back.begin() + few, s);
+	REQUIRE(s == d && std::equal(back.begin(), back.begin() + few, values.begin()));
+	REQUIRE(oroch::hip::varint_device_calls() == before + 3);
+}
+
 template <typename T>
 static void run_type(const char *name)
 {
+	test_varint_sequences<T>();
 	test_stats_select_group<T>();
 	test_sequences<T>();
 	test_blocks<T>();

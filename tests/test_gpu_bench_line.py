@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_complete_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log2n", "22", "--steps", "2",
-                          "--warmup", "1", "--cpu-log2n", "18"], cwd=ROOT, capture_output=True, text=True,
-                         timeout=600)
+                          "--warmup", "1", "--cpu-log2n", "18", "--other-shrink", "8"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -35,6 +35,24 @@ def test_bench_prints_one_complete_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+    # the host is named, and the reference's whole-sequence codecs are timed beside the blocks
+    if c["kind"] == "reference":
+        assert c["cpu_model"] and c["nproc"] >= c["cores"]
+        assert set(k.split()[0] for k in c["whole_array_1thread_GBps"]) == {"bitpck", "bitfor", "bitpfr"}
+        assert "O3_march_native" in c
+    # which compiler built the kernels, and every rank's device
+    assert "clang" in d["built_with"]
+    assert len(d["ranks"]) == 1 and d["ranks"][0]["rank"] == 0 and d["ranks"][0]["ms_per_step"] > 0
+    # a traffic figure is only quoted for the kernels it was measured on
+    assert r["traffic"] is None
+    # the other configurations: every one round-tripped, with both directions priced
+    o = d["other_configs"]
+    assert len(o) == 7 and all(v["round_trip"] == "ok" for v in o.values())
+    for name, v in o.items():
+        assert 0 < v["encode_frac"] < 1 and 0 < v["decode_frac"] < 1, name
+    for head in ("config2 bitpck", "config2 bitfor", "config3 bitpfr", "config3 per-block", "config4 int64",
+                 "config5 int16", "config5 uint64"):
+        assert any(k.startswith(head) for k in o), head
     # the figure of merit is the slower of the two directions
     assert abs(r["frac"] - min(r["encode_path"]["frac"], r["decode_path"]["frac"])) < 1e-9
     assert r["kernel"].split()[0] in ("encode", "decode")
@@ -61,3 +79,27 @@ def test_bench_strong_scaling_of_the_int64_mix():
     # the shards of the two ranks together are the stream of the one
     assert sum(lines[2]["shard_bytes"]) == lines[1]["shard_bytes"][0]
     assert lines[2]["config"]["values_per_gpu"] == (1 << 20)
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_of_the_headline_and_one_rank_per_gpu():
+    """The headline array cut into block ranges for two ranks (sharing this box's GPU
+    on request), every rank's device and time in the line; without the request,
+    more ranks than GPUs is refused before anything is timed."""
+    import torch
+
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", "strong", "--log2n", "21", "--steps", "2",
+            "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end", "--gpus", "2", "--backend", "gloo"]
+    env = dict(os.environ, MASTER_PORT="29534")
+    out = subprocess.run(base + ["--one-device"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["dtype"] == "int32"
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["values"] == 1 << 20 for r in d["ranks"])
+    assert all(r["device"] == 0 and r["ms_per_step"] > 0 for r in d["ranks"])
+    assert d["ms_per_step"] >= max(r["ms_per_step"] for r in d["ranks"]) - 1e-6
+    if torch.cuda.device_count() < 2:
+        env = dict(os.environ, MASTER_PORT="29535")
+        out = subprocess.run(base, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode != 0
+        assert "one rank per GPU" in out.stderr + out.stdout

@@ -310,56 +310,6 @@ def test_argument_errors(hip):
         hip.bitpfr_encode(x, 0, 32)
 
 
-def test_two_pass_path_matches_single_pass(hip, oracle):
-    # the single-pass kernel (chained scan inside one launch) and the two-pass
-    # path (select, scan, encode as separate launches) give the same stream
-    a = np.concatenate([dg.outlier_mix(256 * 999 + 17, np.int32, seed=11, shift=-200),
-                        dg.fuzz_block(np.random.default_rng(5), np.int32, 256)])
-    x = dev(a)
-    s1, o1 = hip.group_encode(x)
-    with hip.option("encode_path", 2):
-        s2, o2 = hip.group_encode(x)
-        big = dev(dg.outlier_mix(1 << 24, np.int32, seed=12, shift=-200))
-        b2, bo2 = hip.group_encode(big)
-    b1, bo1 = hip.group_encode(big)
-    assert np.array_equal(host(bo1), host(bo2)) and np.array_equal(host(b1), host(b2))
-    assert np.array_equal(host(o1), host(o2)) and np.array_equal(host(s1), host(s2))
-    exp, exp_offs = oracle.blocks_encode(a, 256, 16)
-    assert np.array_equal(host(s1), exp) and np.array_equal(host(o1).astype(np.uint64), exp_offs)
-
-
-@pytest.mark.parametrize("dt", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64])
-def test_four_block_single_launch_matches_oracle(hip, oracle, dt):
-    # the single-launch encoder with four blocks per wavefront (workgroups that
-    # exchange the sizes of their tiles through a table of rows) writes the
-    # stream of the oracle for whole, ragged and short inputs; 64-bit types
-    # take the one-block single-launch kernel under the same setting
-    rng = np.random.default_rng(21)
-    parts = [dg.outlier_mix(256 * 12 * 7 + 256 * 3 + 41, dt, seed=4, shift=-100 if np.dtype(dt).kind == "i" else 0)]
-    parts += [dg.fuzz_block(rng, dt, 256) for _ in range(150)]
-    parts.append(dg.fuzz_block(rng, dt, 77))
-    whole = np.concatenate(parts)
-    for a in (whole, whole[:1], whole[:255], whole[:256], whole[:257], whole[:256 * 4 * 12 + 1]):
-        with hip.option("encode_path", 3):
-            s, o = hip.group_encode(dev(a))
-        exp, exp_offs = oracle.blocks_encode(a, 256, 16)
-        assert np.array_equal(host(o).astype(np.uint64), exp_offs)
-        assert np.array_equal(host(s), exp)
-
-
-def test_four_block_single_launch_large(hip):
-    # many rounds per workgroup: same bytes as the separate launches, and back
-    for a in (dg.outlier_mix((1 << 24) + 256 * 5 + 3, np.int32, seed=12, shift=-200),
-              dg.uniform_bits(1 << 22, np.uint32, 5, 13)):
-        x = dev(a)
-        with hip.option("encode_path", 1):
-            s1, o1 = hip.group_encode(x)
-        with hip.option("encode_path", 3):
-            s3, o3 = hip.group_encode(x)
-        assert np.array_equal(host(o1), host(o3)) and np.array_equal(host(s1), host(s3))
-        assert np.array_equal(host(hip.group_decode(s3, o3, a.size, a.dtype)), a)
-
-
 @pytest.mark.parametrize("dt", dg.DTYPES)
 def test_block_statistics_against_oracle(hip, oracle, dt):
     rng = np.random.default_rng(77 + dg.DTYPES.index(dt))

@@ -32,6 +32,3 @@ DT=int32 KIND=uniform BODY=13 LOG2N=28 stats int32_uniform13 python3 $R/tools/ti
 stats sequences python3 $R/tools/time_sequences.py
 grep -h "frac of 8TB/s\|of 8 TB/s" $DEST/int16.log $DEST/uint64.log $DEST/int32_uniform13.log $DEST/sequences.log > $DEST/${TAG}_other_inputs.txt
 ls -la $DEST
-# the single-launch encoder beside the separate launches (encode only, 2^28 values)
-LOG2N=28 timeout -k 10 200 python3 $R/tools/check_fused.py > $DEST/fused.log 2>&1 || true
-tail -n 1 $DEST/fused.log > $DEST/${TAG}_single_launch.txt

@@ -12,7 +12,10 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(d, counter):
@@ -33,8 +36,10 @@ def main(fetch_dir, write_dir, commit=None):
         rd = 2.0 * 1024.0 * fetch.get(k, 0.0)
         wr = 1024.0 * write.get(k, 0.0)
         out[k] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
+    import oroch_amd.sources as sources
+
     json.dump({"unit": "bytes per launch", "correction": "FETCH_SIZE x 2 (gfx950), KiB -> bytes",
-               "commit": commit, "kernels": out}, sys.stdout, indent=1)
+               "commit": commit, "kernel_sources": sources.digest(), "kernels": out}, sys.stdout, indent=1)
     print()
 
 
