@@ -365,6 +365,120 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 }
 
 
+// varint.h:140-147 for the varint and varfor blocks of a quad (integer_codec.h
+// :628-640: the zigzag or the origin value codec), which the path above leaves
+// out: two blocks at a time, 32 lanes to a block.  A lane takes a run of the
+// block's bytes, counts the values that end in it (a byte with its top bit
+// clear ends one), learns from a scan which value its run starts in the middle
+// of, and walks its bytes; the run before it ends at most four bytes into a
+// value, which the lane picks up from there.  The values go through the slots
+// to sink() as above.  skip: blocks already decoded.  Returns the blocks done.
+template <typename E, typename Sink>
+__device__ __forceinline__ uint32_t decode_quad_varints(const uint32_t *qbuf, uint32_t qbytes, uint32_t rel,
+							     uint32_t skip, int lane, typename E::C *slots, Sink &&sink)
+{
+	using C = typename E::C;
+	static_assert(sizeof(C) == 4, "element types up to 32 bits");
+	const uint8_t *qb = reinterpret_cast<const uint8_t *>(qbuf);
+	asm volatile("" : "+v"(lane)); // see decode_quad_fast
+	const int g = int(uint32_t(lane) >> 4);
+	const uint32_t r0 = lane_gather(rel, g), r1 = lane_gather(rel, g + 1);
+	const uint32_t len = r1 - r0;
+	const bool inside = r0 + 16u <= qbytes && r1 <= qbytes && r0 < r1;
+	// [enc] or [enc][origin varint <= 5 bytes], then zeros up to byte 8 (integer_group.h:70-72)
+	const uint2 h = *reinterpret_cast<const uint2 *>(qb + (inside ? r0 : 0u));
+	const uint32_t enc = h.x & 0xffu;
+	// (a value takes a byte at least)
+	const bool vok = inside && (enc == OROCH_VARINT || enc == OROCH_VARFOR) && len >= 8u + uint32_t(BLOCK) &&
+			 !((skip >> g) & 1u);
+	const uint32_t todo = group_mask(__ballot(vok));
+	if (todo == 0)
+		return 0;
+	bool more;
+	uint32_t olen;
+	uint32_t zo = varint4(__builtin_amdgcn_alignbyte(h.y, h.x, 1), &more, &olen);
+	if (more)
+		zo |= ((h.y >> 8) & 0x0fu) << 28;
+	const uint32_t origin = unzz<E>(zo & E::MASK);
+
+	const bool upper = (uint32_t(lane) >> 5) != 0;
+	const uint32_t l32 = uint32_t(lane) & 31u;
+#pragma unroll
+	for (int half = 0; half < 2; half++) {
+		if ((todo & (3u << (2 * half))) == 0)
+			continue;
+		// what the lanes of my block's group know about it
+		auto of_block = [&](uint32_t x) {
+			const uint32_t a = read_lane(x, 2 * half * GROUP), b = read_lane(x, (2 * half + 1) * GROUP);
+			return upper ? b : a;
+		};
+		const bool mine = of_block(uint32_t(vok)) != 0;
+		const uint32_t at0 = of_block(r0) + 8u, blen = of_block(len) - 8u;
+		// bytes per lane: a multiple of four; 32 of them cover the block's image
+		const uint32_t run = mine ? (((blen + 31u) >> 5) + 3u) & ~3u : 0u;
+		const uint32_t first = at0 + __umul24(l32, run), stop = at0 + blen;
+		const uint32_t nd = wave_max(run >> 2);
+		uint32_t ends_here = 0;
+		for (uint32_t k = 0; k < nd; k++) {
+			const uint32_t o = first + 4u * k;
+			const bool live = 4u * k < run && o < stop;
+			const uint32_t w = live ? qbuf[o >> 2] : 0x80808080u;
+			ends_here += uint32_t(__popc(~w & 0x80808080u));
+		}
+		// values that end before my run, over the 32 lanes of the block
+		uint32_t before = row_scan_sum(ends_here);
+		before += dpp_mov<0x142, 0xa>(0u, before);
+		uint32_t rank = before - ends_here;
+		// the bytes of the value under way where my run starts: what follows the
+		// last ending byte among the four bytes before it
+		uint32_t acc = 0, shift = 0;
+		if (mine && l32 != 0 && first < stop) {
+			const uint32_t p = qbuf[(first >> 2) - 1u];
+			const uint32_t t = ~p & 0x80808080u;
+			const uint32_t keep = t ? uint32_t(__clz(t)) >> 3 : 4u;
+			const uint32_t tailb = keep ? p >> (8u * (4u - keep)) : 0u;
+			acc = (tailb & 0x7fu) | ((tailb >> 1) & 0x3f80u) | ((tailb >> 2) & 0x1fc000u) |
+			      ((tailb >> 3) & 0xfe00000u);
+			shift = 7u * keep;
+		}
+		C *vals = slots + (upper ? SLOT_STRIDE : 0);
+		for (uint32_t k = 0; k < nd; k++) {
+			const uint32_t o = first + 4u * k;
+			const bool live = mine && 4u * k < run && o < stop;
+			const uint32_t w = live ? qbuf[o >> 2] : 0x80808080u;
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const uint32_t byte = (w >> (8 * b)) & 0xffu;
+				acc |= shift < 32u ? (byte & 0x7fu) << shift : 0u;
+				shift += 7u;
+				if (live && !(byte & 0x80u)) {
+					if (rank < uint32_t(BLOCK))
+						vals[rank] = C(acc);
+					rank++;
+					acc = 0;
+					shift = 0;
+				}
+			}
+		}
+		wave_sync();
+#pragma unroll
+		for (int s = 2 * half; s < 2 * half + 2; s++) {
+			if (!((todo >> s) & 1u))
+				continue;
+			const uint32_t org = read_lane(origin, s * GROUP);
+			const uint32_t e = read_lane(enc, s * GROUP);
+			const uint4 q = *reinterpret_cast<const uint4 *>(&slots[(s & 1) * SLOT_STRIDE + lane * VPL]);
+			C v[VPL] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+			for (int i = 0; i < VPL; i++)
+				v[i] = e == OROCH_VARINT ? unzz<E>(v[i] & E::MASK) : C((v[i] + org) & E::MASK);
+			sink(s, lane, v);
+		}
+		wave_sync();
+	}
+	return todo;
+}
+
 // Persistent wavefronts over quads of blocks; offsets are fetched two quads
 // ahead and the quad's bytes one quad ahead (the first 3 KiB of them, into
 // registers), so the dependent latencies overlap with decoding.  The loop is
@@ -503,7 +617,11 @@ __device__ __forceinline__ void walk_quads(const uint8_t *__restrict__ src,
 				qbuf, total0, rel0, lane, slots, endss[wave], wt,
 				[&](int s, int ln, const C(&v)[VPL]) { sink(blk0 + size_t(s), BLOCK, ln, v); }, advance);
 		if (done != 15u) {
-			// the others one by one, from the same staged bytes
+			// varint blocks together, the others one by one, from the same staged bytes
+			if (blk0 + QUAD <= nblocks && base + size_t(QUAD) * BLOCK <= n)
+				done |= decode_quad_varints<E>(
+					qbuf, total0, rel0, done, lane, slots,
+					[&](int s, int ln, const C(&v)[VPL]) { sink(blk0 + size_t(s), BLOCK, ln, v); });
 			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
 				if ((done >> b) & 1u)
 					continue;

@@ -6,8 +6,9 @@
 // slot array, from which lane p of the wavefront packs 16-byte word p of the
 // quad with compile-time field positions and stores it straight to the stream.
 // The header is produced one byte per lane, exception lists are written by
-// the lanes that own exceptions.  Covers bitpck, bitfor and bitpfr blocks of
-// one common width; anything else goes block by block through encode_block.
+// the lanes that own exceptions.  Covers bitpck, bitfor and bitpfr blocks from
+// four bits up; varint and varfor blocks of the quad follow in a pass of their
+// own; anything else goes block by block through encode_block.
 //
 // Included by group.hip after encode_block and decode_quad.hpp; 8-, 16- and
 // 32-bit element types.
@@ -273,6 +274,111 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 	return fast;
 }
 
+// The varint and varfor blocks of a quad (varint.h:133-139 with the zigzag or
+// the origin value codec, integer_codec.h:511-518), which the path above
+// leaves out.  Every lane lays the varints of its sixteen values end to end
+// into the block's slots, which serve as the staging area of its bytes, and
+// the area goes to the stream with the zero padding up to the block's 16-byte
+// boundary.  Loads its own operands: it runs off the main path.  Returns the
+// blocks done.
+template <typename E>
+__device__ __forceinline__ uint32_t encode_quad_varints(const typename E::S *__restrict__ src,
+							     const oroch_block_desc *__restrict__ desc,
+							     const uint64_t *__restrict__ offsets, size_t blk0, int lane,
+							     typename E::C *slots, uint8_t *__restrict__ dst)
+{
+	using C = typename E::C;
+	static_assert(sizeof(C) == 4, "element types up to 32 bits");
+	asm volatile("" : "+v"(lane)); // see decode_quad_fast
+	const int g = int(uint32_t(lane) >> 4), sub = int(uint32_t(lane) & 15u);
+	const size_t blk = blk0 + size_t(g);
+	const uint4 *dq = reinterpret_cast<const uint4 *>(desc + blk);
+	const uint4 da = dq[0], db = dq[1];
+	const C origin = da.x;
+	const uint32_t dataspace = da.z, size = da.w;
+	const uint32_t metaspace = db.x & 0xffffu;
+	const uint32_t enc = (db.y >> 16) & 0xffu;
+	const uint32_t doff = (metaspace + 7u) & ~7u; // integer_group.h:50-52
+	const bool vok = (enc == OROCH_VARINT || enc == OROCH_VARFOR) && doff == 8u &&
+			 dataspace + 16u <= uint32_t(sizeof(C)) * SLOT_STRIDE && size >= doff + dataspace;
+	const uint32_t todo = group_mask(__ballot(vok));
+	if (todo == 0)
+		return 0;
+	uint8_t *out = dst + offsets[blk];
+	C u[VPQ];
+	load16<E>(src + blk * BLOCK + size_t(sub) * VPQ, u);
+	uint32_t *stage = reinterpret_cast<uint32_t *>(slots + __umul24(uint32_t(g), SLOT_STRIDE));
+	// zeros: the varints are OR-ed in, and what follows them is padding
+	static_assert(SLOT_STRIDE * sizeof(C) == (BLOCK + 2 * GROUP) * 4, "the stores below cover the slots");
+#pragma unroll
+	for (int k = 0; k < VPQ / 4; k++)
+		*reinterpret_cast<uint4 *>(&stage[sub * VPQ + 4 * k]) = make_uint4(0, 0, 0, 0);
+	*reinterpret_cast<uint2 *>(&stage[BLOCK + 2 * sub]) = make_uint2(0, 0);
+	// bytes of a varint: ceil(L / 7) = (37 L + 219) >> 8 for a bit length L in 1..32
+	auto nbytes = [](uint32_t x) { return (uint32_t(__umul24(bitlen(x | 1u), 37u)) + 219u) >> 8; };
+	uint32_t count = 0;
+#pragma unroll
+	for (int i = 0; i < VPQ; i++) {
+		u[i] = enc == OROCH_VARINT ? zz<E>(u[i]) : C((u[i] - origin) & E::MASK);
+		count += nbytes(u[i]);
+	}
+	count = vok ? count : 0u;
+	const uint32_t at = row_scan_sum(count) - count; // my first byte
+	wave_sync();
+	if (vok) {
+		uint32_t word = at >> 2, fill = at & 3u; // dword under way, bytes it has
+		uint64_t acc = 0;
+#pragma unroll
+		for (int i = 0; i < VPQ; i++) {
+			const uint32_t x = u[i];
+			const uint32_t nby = nbytes(x);
+			// the seven-bit groups a byte apart, continuation bits on all but the last
+			const uint32_t lo = (x & 0x7fu) | ((x << 1) & 0x7f00u) | ((x << 2) & 0x7f0000u) |
+					    ((x << 3) & 0x7f000000u);
+			const uint32_t cont = 0x80808080u & ((nby > 4u ? 0u : 1u << (8u * (nby - 1u))) - 1u);
+			uint64_t w = lo | cont;
+			if constexpr (E::W > 28)
+				w |= uint64_t(x >> 28) << 32;
+			acc |= w << (8u * fill);
+			fill += nby;
+			if (fill >= 4u) {
+				atomicOr(&stage[word++], uint32_t(acc));
+				acc >>= 32;
+				fill -= 4u;
+			}
+			if constexpr (E::W > 21) {
+				// (three bytes under way and a five-byte value make eight)
+				if (fill >= 4u) {
+					atomicOr(&stage[word++], uint32_t(acc));
+					acc >>= 32;
+					fill -= 4u;
+				}
+			}
+		}
+		if (fill)
+			atomicOr(&stage[word], uint32_t(acc));
+	}
+	wave_sync();
+	if (vok) {
+		// metadata, integer_codec.h:128-151: [enc] or [enc][origin varint], zeros up to byte 8
+		if (sub == 0) {
+			const uint32_t zo = zz<E>(origin);
+			const uint32_t nby = nbytes(zo);
+			const uint32_t lo = (zo & 0x7fu) | ((zo << 1) & 0x7f00u) | ((zo << 2) & 0x7f0000u) |
+					    ((zo << 3) & 0x7f000000u);
+			const uint32_t cont = 0x80808080u & ((nby > 4u ? 0u : 1u << (8u * (nby - 1u))) - 1u);
+			uint64_t hd = (uint64_t(zo >> 28) << 32) | lo | cont;
+			hd = enc == OROCH_VARFOR ? hd << 8 : 0;
+			*reinterpret_cast<uint2 *>(out) = make_uint2(uint32_t(hd) | enc, uint32_t(hd >> 32));
+		}
+		const uint8_t *bytes = reinterpret_cast<const uint8_t *>(stage);
+		for (uint32_t k = uint32_t(sub) * 8u; k < size - doff; k += GROUP * 8u)
+			*reinterpret_cast<uint2 *>(out + doff + k) = *reinterpret_cast<const uint2 *>(bytes + k);
+	}
+	wave_sync();
+	return todo;
+}
+
 // The kernel is latency-bound (dependent LDS round trips per quad), so it is
 // shaped for occupancy: registers capped for six wavefronts per SIMD, and the
 // one-block path's image shares LDS with the slots (the two are never live
@@ -299,9 +405,13 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 		const size_t blk0 = q * QUAD;
 		uint32_t done = 0;
 		if (blk0 + QUAD <= nblocks && (blk0 + QUAD) * BLOCK <= n) {
-			const size_t blk = blk0 + size_t(uint32_t(lane) >> 4);
+			// (an opaque lane number: the address arithmetic stays in the loop
+			// instead of in registers that live across it)
+			int ln = lane;
+			asm volatile("" : "+v"(ln));
+			const size_t blk = blk0 + size_t(uint32_t(ln) >> 4);
 			C v[VPQ];
-			load16<E>(src + blk * BLOCK + size_t(uint32_t(lane) & 15u) * VPQ, v);
+			load16<E>(src + blk * BLOCK + size_t(uint32_t(ln) & 15u) * VPQ, v);
 			const uint4 *dq = reinterpret_cast<const uint4 *>(desc + blk);
 			const uint4 da = dq[0], db = dq[1];
 			const uint64_t off = offsets[blk];
@@ -309,6 +419,8 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_WG) __attribute__((amdgpu_waves_per
 						   wt, dst);
 		}
 		if (done != 15u) {
+			if (blk0 + QUAD <= nblocks && (blk0 + QUAD) * BLOCK <= n)
+				done |= encode_quad_varints<E>(src, desc, offsets, blk0, lane, slotss[wave], dst);
 			for (int b = 0; b < QUAD && blk0 + size_t(b) < nblocks; b++) {
 				if ((done >> b) & 1u)
 					continue;

@@ -12,7 +12,8 @@ dev = torch.device("cuda", 0)
 unsigned64 = dt == "uint64"  # generated as int64 bit patterns, handed over as uint64
 tdt = getattr(torch, "int64" if unsigned64 else dt)
 if kind == "outlier":
-    x = devgen.outlier_mix(n, tdt, 3, dev, body_bits=int(os.environ.get("BODY", "10")), out_bits=int(os.environ.get("OUT", "28")), shift=-200)
+    x = devgen.outlier_mix(n, tdt, int(os.environ.get("SEED", "3")), dev, body_bits=int(os.environ.get("BODY", "10")), out_bits=int(os.environ.get("OUT", "28")), shift=int(os.environ.get("SHIFT", "-200")),
+                           **({"permille": int(os.environ["PERMILLE"])} if "PERMILLE" in os.environ else {}))
 elif kind == "mix":
     x = devgen.block_mix_int64(n, 4, dev).to(tdt)
 else:
