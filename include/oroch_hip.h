@@ -273,11 +273,20 @@ int oroch_group_decode(int dtype, const void *src, const uint64_t *offsets, size
  * first use per device and keeps, in chunks, with copies in, kernels and
  * copies out overlapped.  dst_capacity >= oroch_group_bound(); offsets_host holds
  * ceil(n / block) + 1 entries.  Returns the stream length in *total_host.
+ *
+ * The pipe's chunks are sized for the request: 1 MiB of values at least (about
+ * 5 MiB of device and as much pinned host memory), 64 MiB at most (about 290
+ * and 270 MiB); a later, larger request replaces the pipe by a larger one.  It
+ * is kept until oroch_hip_release_host_buffers(), and the *_host calls of one
+ * device run one at a time.  Callers that want to own this memory, or several
+ * pipes side by side, use oroch_pipe_create.
  */
 int oroch_group_encode_host(int dtype, const void *src_host, size_t n, void *dst_host,
 			    size_t dst_capacity, uint64_t *offsets_host, uint64_t *total_host);
 int oroch_group_decode_host(int dtype, const void *src_host, const uint64_t *offsets_host,
 			    size_t n, void *dst_host);
+/* Frees the pipes behind the two calls above, on every device (they come back on the next call). */
+void oroch_hip_release_host_buffers(void);
 /* oroch_group_select / oroch_group_stats with HOST pointers. */
 int oroch_group_select_host(int dtype, const void *src_host, size_t n,
 			    oroch_block_desc *desc_host);
@@ -326,7 +335,8 @@ int oroch_bitpfr_patch_host(int dtype, void *dst_host, size_t n, uint64_t origin
  * oroch_group_decode_host.  Caller buffers that are pinned (hipHostMalloc,
  * hipHostRegister) go over the link as they are, others through the pipe's
  * staging buffers.  One call at a time per pipe (calls are serialised inside);
- * a pipe belongs to the device that was current when it was made.
+ * a pipe belongs to the device that was current when it was made, and a call
+ * with another device current returns OROCH_E_ARGUMENT.
  */
 typedef struct oroch_pipe oroch_pipe;
 int oroch_pipe_create(size_t chunk_bytes, oroch_pipe **out);

@@ -55,6 +55,7 @@ def _load():
         "oroch_hip_init": (i, [i]),
         "oroch_hip_strerror": (C.c_char_p, [i]),
         "oroch_hip_build_info": (C.c_char_p, []),
+        "oroch_hip_release_host_buffers": (None, []),
         "oroch_bitpck_capacity": (sz, [u32]),
         "oroch_bitpck_space": (sz, [sz, u32]),
         "oroch_bitpck_encode": (i, [i, vp, sz, u32, vp, vp]),

@@ -352,9 +352,9 @@ extern "C" int oroch_group_encode_host(int dtype, const void *src_host, size_t n
 {
 	if (dtype < 0 || dtype > 7)
 		return OROCH_E_DTYPE;
-	oroch_pipe *pipe = nullptr;
-	const int rc = oroch_hip::default_pipe(&pipe);
-	return rc ? rc : oroch_pipe_encode(pipe, dtype, src_host, n, dst_host, dst_capacity, offsets_host, total_host);
+	return oroch_hip::with_default_pipe(n << (dtype >> 1), [&](oroch_pipe *pipe) {
+		return oroch_pipe_encode(pipe, dtype, src_host, n, dst_host, dst_capacity, offsets_host, total_host);
+	});
 }
 
 extern "C" int oroch_group_decode_host(int dtype, const void *src_host,
@@ -364,9 +364,9 @@ extern "C" int oroch_group_decode_host(int dtype, const void *src_host,
 		return OROCH_E_DTYPE;
 	if (n == 0)
 		return 0;
-	oroch_pipe *pipe = nullptr;
-	const int rc = oroch_hip::default_pipe(&pipe);
-	return rc ? rc : oroch_pipe_decode(pipe, dtype, src_host, offsets_host, n, dst_host);
+	return oroch_hip::with_default_pipe(n << (dtype >> 1), [&](oroch_pipe *pipe) {
+		return oroch_pipe_decode(pipe, dtype, src_host, offsets_host, n, dst_host);
+	});
 }
 
 extern "C" int oroch_group_select_host(int dtype, const void *src_host, size_t n,

@@ -978,9 +978,11 @@ static int insert_value(oroch_array *a, uint64_t index, uint64_t value)
 	    (rc = int(hipMemcpy(mv + (at + 1) * w, v + at * w, (cnt - at) * w, hipMemcpyDeviceToDevice))) ||
 	    (rc = int(hipMemcpy(last, mv + cnt * w, w, hipMemcpyDeviceToHost))))
 		return rc;
-	// The new images are made beside the old ones and take their place only when
-	// everything that can fail has succeeded: a failure on the way leaves the
-	// array as it was.
+	// The new images and their offsets (rebased onto the stream) are made beside
+	// the old ones; every allocation, kernel and synchronisation is over before
+	// the array is touched.  What then remains are two device-to-device copies
+	// into memory the array already owns; short of losing the device they do not
+	// fail, and a failure of anything before them leaves the array as it was.
 	const size_t nb = cnt / BLOCK;
 	const size_t bound = oroch_group_bound(a->dtype, cnt), wsb = oroch_group_workspace(a->dtype, cnt);
 	dev_buf images, piece, ws;
@@ -992,12 +994,14 @@ static int insert_value(oroch_array *a, uint64_t index, uint64_t value)
 		return rc;
 	a->tail.reserve(a->tail.size() + w); // may throw, before anything has changed
 	const unsigned grid = unsigned((nb + 1 + 255) / 256 < 1024 ? (nb + 1 + 255) / 256 : 1024);
-	if ((rc = int(hipMemcpy(static_cast<uint8_t *>(a->stream.p) + cut, images.p, size_t(total),
-				hipMemcpyDeviceToDevice))))
-		return rc;
 	hipLaunchKernelGGL(k_rebase, dim3(grid), dim3(256), 0, nullptr, static_cast<const uint64_t *>(piece.p), nb + 1,
-			   cut, static_cast<uint64_t *>(a->offsets.p) + g);
+			   cut, static_cast<uint64_t *>(piece.p));
 	if ((rc = int(hipGetLastError())) || (rc = int(hipStreamSynchronize(nullptr))))
+		return rc;
+	if ((rc = int(hipMemcpy(static_cast<uint8_t *>(a->stream.p) + cut, images.p, size_t(total),
+				hipMemcpyDeviceToDevice))) ||
+	    (rc = int(hipMemcpy(static_cast<uint64_t *>(a->offsets.p) + g, piece.p, (nb + 1) * sizeof(uint64_t),
+				hipMemcpyDeviceToDevice))))
 		return rc;
 	a->stream_bytes = size_t(cut) + size_t(total);
 	a->tail.insert(a->tail.begin(), last, last + w);

@@ -1,5 +1,6 @@
 // host_util.hpp -- host-side helpers shared by the files that implement the C ABI.
 #pragma once
+#include <functional>
 
 #include <cstddef>
 #include <cstdint>
@@ -51,9 +52,10 @@ inline size_t container_stream_offset(size_t nblocks)
 // buffers; returns after the data has arrived.  (api.hip)
 int staged_copy(void *dst, const void *src, size_t bytes, bool to_device, hipStream_t st);
 
-// The pipe behind the *_host entry points of the current device, made on first
-// use.  (pipeline.hip)
-int default_pipe(oroch_pipe **out);
+// Runs fn with the pipe behind the *_host entry points of the current device
+// (made on first use, its chunks sized for `bytes` of values, kept), under that
+// device's lock.  (pipeline.hip)
+int with_default_pipe(size_t bytes, const std::function<int(oroch_pipe *)> &fn);
 
 // memcpy by a few threads (pageable <-> pinned copies are bound by one core otherwise).  (api.hip)
 void parallel_memcpy(void *dst, const void *src, size_t bytes);

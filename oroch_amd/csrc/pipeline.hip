@@ -158,16 +158,31 @@ extern "C" void oroch_pipe_destroy(oroch_pipe *p)
 {
 	if (!p)
 		return;
-	(void) hipDeviceSynchronize();
+	// whatever the pipe still has in flight (the current device may be another)
+	if (p->s_in) (void) hipStreamSynchronize(p->s_in);
+	if (p->s_run) (void) hipStreamSynchronize(p->s_run);
+	if (p->s_out) (void) hipStreamSynchronize(p->s_out);
 	pipe_free(p);
 }
+
+namespace {
+
+// A pipe's buffers and streams live on the device it was made on; the kernels
+// are launched on the current one.
+bool on_pipes_device(const oroch_pipe *p)
+{
+	int device = -1;
+	return hipGetDevice(&device) == hipSuccess && device == p->device;
+}
+
+} // namespace
 
 extern "C" int oroch_pipe_encode(oroch_pipe *p, int dtype, const void *src_host, size_t n, void *dst_host,
 				 size_t dst_capacity, uint64_t *offsets_host, uint64_t *total_host)
 {
 	if (dtype < 0 || dtype > 7)
 		return OROCH_E_DTYPE;
-	if (!p || !offsets_host || !total_host || (n && (!src_host || !dst_host)))
+	if (!p || !offsets_host || !total_host || (n && (!src_host || !dst_host)) || !on_pipes_device(p))
 		return OROCH_E_ARGUMENT;
 	std::lock_guard<std::mutex> guard(p->lock);
 	no_profile_scope quiet; // events of the recorder belong to the caller's stream
@@ -272,7 +287,7 @@ extern "C" int oroch_pipe_decode(oroch_pipe *p, int dtype, const void *src_host,
 		return OROCH_E_DTYPE;
 	if (n == 0)
 		return 0;
-	if (!p || !src_host || !offsets_host || !dst_host)
+	if (!p || !src_host || !offsets_host || !dst_host || !on_pipes_device(p))
 		return OROCH_E_ARGUMENT;
 	std::lock_guard<std::mutex> guard(p->lock);
 	no_profile_scope quiet;
@@ -357,21 +372,47 @@ extern "C" int oroch_pipe_decode(oroch_pipe *p, int dtype, const void *src_host,
 	return rc;
 }
 
-// The pipe behind oroch_group_encode_host / oroch_group_decode_host: one per
-// device, made on first use and kept.
-int oroch_hip::default_pipe(oroch_pipe **out)
+// The pipes behind oroch_group_encode_host / oroch_group_decode_host: one per
+// device, made on first use, sized for the request (chunks of 1 MiB at least,
+// 64 MiB at most; a larger request later makes a larger pipe in its place) and
+// kept until oroch_hip_release_host_buffers().  A call holds the device's lock
+// from the look-up to its end, so a pipe is never replaced or freed under a
+// caller.
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex default_locks[MAX_DEVICES];
+oroch_pipe *default_pipes[MAX_DEVICES] = {};
+} // namespace
+
+int oroch_hip::with_default_pipe(size_t bytes, const std::function<int(oroch_pipe *)> &fn)
 {
-	static std::mutex lock;
-	static oroch_pipe *pipes[64] = {};
 	int device = 0;
 	int rc = int(hipGetDevice(&device));
 	if (rc)
 		return rc;
-	if (device < 0 || device >= 64)
+	if (device < 0 || device >= MAX_DEVICES)
 		return OROCH_E_ARGUMENT;
-	std::lock_guard<std::mutex> guard(lock);
-	if (!pipes[device] && (rc = oroch_pipe_create(0, &pipes[device])))
+	size_t chunk = size_t(1) << 20;
+	while (chunk < bytes && chunk < (size_t(64) << 20))
+		chunk <<= 1;
+	std::lock_guard<std::mutex> guard(default_locks[device]);
+	oroch_pipe *&p = default_pipes[device];
+	if (p && p->chunk_bytes < chunk) {
+		oroch_pipe_destroy(p);
+		p = nullptr;
+	}
+	if (!p && (rc = oroch_pipe_create(chunk, &p)))
 		return rc;
-	*out = pipes[device];
-	return 0;
+	return fn(p);
+}
+
+extern "C" void oroch_hip_release_host_buffers(void)
+{
+	for (int device = 0; device < MAX_DEVICES; device++) {
+		std::lock_guard<std::mutex> guard(default_locks[device]);
+		if (default_pipes[device]) {
+			oroch_pipe_destroy(default_pipes[device]);
+			default_pipes[device] = nullptr;
+		}
+	}
 }

@@ -410,6 +410,11 @@ int put_list(unsigned encoding, unsigned nbits, const uint64_t *list, size_t k, 
 		at += bytes;
 		return rc;
 	}
+	// A list left at 'normal' (a descriptor nobody filled in) would be raw
+	// size_t / unsigned values in the reference (integer_codec.h:573-580 through
+	// encode_basic), a form no header can announce (:196-204): refused.
+	if (encoding != OROCH_VARINT)
+		return OROCH_E_ARGUMENT;
 	dev_buf tmp, ws;
 	const size_t wsb = oroch_varint_workspace(k);
 	uint64_t bytes = 0;
@@ -451,6 +456,8 @@ int get_list(unsigned encoding, unsigned nbits, const uint8_t *src, size_t src_b
 		at += bytes;
 		return rc;
 	}
+	if (encoding != OROCH_VARINT)
+		return OROCH_E_ARGUMENT; // see put_list
 	// varints: at most ten bytes each, and no more than what is there
 	size_t avail = src_bytes - size_t(at);
 	avail = avail < k * 10 ? avail : k * 10;

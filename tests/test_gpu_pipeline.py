@@ -67,7 +67,44 @@ def test_pipeline_with_pinned_buffers_and_default_pipe(hip, oracle):
     assert np.array_equal(stream2, exp) and np.array_equal(offs2, exp_offs)
     assert np.array_equal(pipe.decode(exp, exp_offs, n, np.int32, out=pback.numpy()), a)
     pipe.close()
-    # the *_host entry points run through the library's own pipe (64 MiB chunks)
+    # the *_host entry points run through the library's own pipe
     s3, o3 = hip.group_encode_host(a)
     assert np.array_equal(s3, exp) and np.array_equal(o3, exp_offs)
     assert np.array_equal(hip.group_decode_host(s3, o3, n, np.int32), a)
+
+
+def test_library_pipe_is_sized_for_the_request_and_can_be_released(hip, oracle):
+    """The pipe behind the *_host calls starts small (a block of values must not
+    cost hundreds of MiB), is replaced by a larger one when a larger array comes,
+    and goes away on request; results are the same throughout."""
+    import torch
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    hip.lib.oroch_hip_release_host_buffers()
+    before = free_bytes()
+    small = dg.outlier_mix(200, np.int16, seed=3, shift=-9)
+    e, eo = oracle.blocks_encode(small, 256, 16)
+    s, o = hip.group_encode_host(small)
+    assert np.array_equal(s, e) and np.array_equal(o, eo)
+    assert np.array_equal(hip.group_decode_host(s, o, small.size, np.int16), small)
+    held_small = before - free_bytes()
+    assert held_small < (64 << 20), held_small
+    n = (1 << 23) + 77   # 32 MiB of values: a pipe with larger chunks takes over
+    big = dg.outlier_mix(n, np.int32, seed=4, shift=-200)
+    e, eo = oracle.blocks_encode(big, 256, 16)
+    s, o = hip.group_encode_host(big)
+    assert np.array_equal(s, e) and np.array_equal(o, eo)
+    assert np.array_equal(hip.group_decode_host(s, o, n, np.int32), big)
+    held_big = before - free_bytes()
+    assert held_big > held_small
+    # small again: served by the pipe that is there
+    s, o = hip.group_encode_host(small)
+    assert np.array_equal(hip.group_decode_host(s, o, small.size, np.int16), small)
+    hip.lib.oroch_hip_release_host_buffers()
+    assert before - free_bytes() < (8 << 20)
+    s, o = hip.group_encode_host(small)
+    assert np.array_equal(hip.group_decode_host(s, o, small.size, np.int16), small)
+    hip.lib.oroch_hip_release_host_buffers()

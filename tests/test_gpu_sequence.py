@@ -156,6 +156,17 @@ def test_encode_honours_the_callers_metadata(hip, oracle, dt, n):
     m, d = both(encoding=BITPFR, origin=mn, nbits=3, noutliers=1, index_encoding=VARINT, value_encoding=VARINT)
     with pytest.raises(hip.OrochError):
         hip.sequence_encode(x, d, capacity=n * 16)
+    # exception lists left at 'normal' (a descriptor nobody filled in) are refused: the
+    # reference would write raw words there, a form no header announces
+    u = (raw - np.uint64(mn)) & np.uint64(mask)
+    k = int(np.count_nonzero(u >> np.uint64(3)))
+    if k:
+        for ie, ve in ((NORMAL, VARINT), (VARINT, NORMAL), (NORMAL, NORMAL)):
+            m, d = both(encoding=BITPFR, origin=mn, nbits=3, noutliers=k, index_encoding=ie, value_encoding=ve)
+            with pytest.raises(hip.OrochError):
+                hip.sequence_encode(x, d, capacity=n * 16)
+            with pytest.raises(hip.OrochError):
+                hip.sequence_decode(dev(np.zeros(n * 16, np.uint8)), n, d, dt)
     # and too little room is an error, not an overrun
     m, d = both(encoding=NORMAL)
     with pytest.raises(hip.OrochError):
