@@ -18,10 +18,10 @@ stats() { # <name> <program and arguments ...>
 	local f=$(find $DEST/raw_$name -name "*kernel_stats.csv" | head -n 1)
 	(head -n 1 $f; grep oroch_hip $f) > $DEST/${TAG}_${name}_kernel_stats.csv
 }
-stats headline python3 $R/bench.py --steps 20 --no-cpu-baseline --no-end-to-end
+stats headline python3 $R/bench.py --steps 20 --no-cpu-baseline --no-end-to-end --no-other-configs
 grep '^{' $DEST/headline.log | tail -n 1 > $DEST/${TAG}_bench.json
 for c in FETCH_SIZE WRITE_SIZE; do
-	timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d $DEST/pmc_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $DEST/pmc_$c.log 2>&1
+	timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d $DEST/pmc_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-other-configs > $DEST/pmc_$c.log 2>&1
 done
 python3 $R/tools/pmc_traffic.py $DEST/pmc_FETCH_SIZE $DEST/pmc_WRITE_SIZE $COMMIT > $DEST/traffic_int32_2p30.json
 stats int64mix python3 $R/bench.py --config int64mix --steps 10 --no-cpu-baseline --no-end-to-end
@@ -29,6 +29,9 @@ grep '^{' $DEST/int64mix.log | tail -n 1 > $DEST/${TAG}_int64mix_bench.json
 DT=int16 KIND=outlier BODY=9 OUT=15 LOG2N=29 stats int16 python3 $R/tools/time_any.py
 DT=uint64 KIND=outlier BODY=20 OUT=50 LOG2N=28 stats uint64 python3 $R/tools/time_any.py
 DT=int32 KIND=uniform BODY=13 LOG2N=28 stats int32_uniform13 python3 $R/tools/time_any.py
+DT=int16 KIND=outlier BODY=9 OUT=16 PERMILLE=5 SHIFT=-256 SEED=5 LOG2N=28 stats int16_config5 python3 $R/tools/time_any.py
 stats sequences python3 $R/tools/time_sequences.py
-grep -h "frac of 8TB/s\|of 8 TB/s" $DEST/int16.log $DEST/uint64.log $DEST/int32_uniform13.log $DEST/sequences.log > $DEST/${TAG}_other_inputs.txt
+grep -h "frac of 8TB/s\|of 8 TB/s" $DEST/int16.log $DEST/uint64.log $DEST/int32_uniform13.log $DEST/int16_config5.log $DEST/sequences.log > $DEST/${TAG}_other_inputs.txt
+# the bench as the driver runs it (no profiler): the line with every part
+cd $R && timeout -k 10 600 python3 bench.py > $DEST/${TAG}_bench_plain.json 2> $DEST/bench_plain.err
 ls -la $DEST
