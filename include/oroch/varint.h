@@ -14,6 +14,7 @@
 
 #include <iterator>
 #include <type_traits>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -49,8 +50,45 @@ inline const T *contiguous(T *src, T *, std::vector<T> &)
 template <typename T, typename Iter>
 inline const T *contiguous(Iter src, Iter const end, std::vector<T> &keep)
 {
-	keep = gather<T>(src, end);
-	return keep.data();
+	if constexpr (std::is_same<Iter, typename std::vector<T>::iterator>::value ||
+		      std::is_same<Iter, typename std::vector<T>::const_iterator>::value) {
+		return src == end ? nullptr : &*src;
+	} else {
+		keep = gather<T>(src, end);
+		return keep.data();
+	}
+}
+
+// Where n values can be written as one array: the range itself when it is one
+// (then *direct is set), else `keep`, to be copied to the range afterwards.
+template <typename T, typename Iter>
+inline T *writable(Iter dst, size_t n, std::vector<T> &keep, bool *direct)
+{
+	if constexpr (std::is_same<Iter, T *>::value || std::is_same<Iter, typename std::vector<T>::iterator>::value) {
+		*direct = true;
+		return n ? &*dst : nullptr;
+	} else {
+		*direct = false;
+		keep.resize(n);
+		return keep.data();
+	}
+}
+
+// The length of the first n varints at src: they end with the n-th byte whose
+// top bit is clear.  Eight bytes at a time while eight more values are wanted
+// (eight values take eight bytes at least, so those bytes are the caller's).
+inline size_t varint_bytes(const uint8_t *src, size_t n)
+{
+	size_t at = 0, left = n;
+	while (left >= 8) {
+		uint64_t w;
+		std::memcpy(&w, src + at, 8);
+		left -= size_t(__builtin_popcountll(~w & 0x8080808080808080ull));
+		at += 8;
+	}
+	for (; left; at++)
+		left -= (src[at] & 0x80) == 0;
+	return at;
 }
 
 } // namespace hip
@@ -144,16 +182,17 @@ public:
 		if (device_codec && n >= hip::varint_device_threshold) {
 			// The bytes of n values end with the n-th byte that has its top bit
 			// clear; only they are the caller's to read.
-			size_t nbytes = 0;
-			for (size_t left = n; left; nbytes++)
-				left -= (src[nbytes] & 0x80) == 0;
-			std::vector<T> values(n);
+			const size_t nbytes = hip::varint_bytes(src, n);
+			std::vector<T> keep;
+			bool direct;
+			T *values = hip::writable<T>(dst, n, keep, &direct);
 			uint64_t used = 0;
-			hip::check(oroch_varint_decode_host(hip::dtype_of<T>(), src, nbytes, n, values.data(), &used),
+			hip::check(oroch_varint_decode_host(hip::dtype_of<T>(), src, nbytes, n, values, &used),
 				   "varint decode");
 			hip::varint_device_calls()++;
-			for (size_t i = 0; i < n; i++)
-				*dst++ = values[i];
+			if (!direct)
+				for (size_t i = 0; i < n; i++)
+					*dst++ = values[i];
 			src += used;
 			return;
 		}

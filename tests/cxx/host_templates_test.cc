@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <sstream>
+#include <deque>
 #include <vector>
 
 #include <oroch/integer_array.h>
@@ -692,6 +693,26 @@ static void test_varint_sequences()
 	REQUIRE(size_t(s - bytes.data()) == want.size());
 	REQUIRE(back == values);
 	REQUIRE(oroch::hip::varint_device_calls() == before + 3);
+	// ranges that are not arrays go through a copy
+	{
+		std::deque<T> in(values.begin(), values.end()), out(n);
+		REQUIRE(codec::space(in.begin(), in.end()) == want.size());
+		std::fill(bytes.begin(), bytes.end(), uint8_t(0xee));
+		d = bytes.data();
+		codec::encode(d, in.begin(), in.end());
+		REQUIRE(size_t(d - bytes.data()) == want.size());
+		REQUIRE(std::equal(want.begin(), want.end(), bytes.begin()));
+		s = bytes.data();
+		codec::decode(out.begin(), out.end(), s);
+		REQUIRE(size_t(s - bytes.data()) == want.size());
+		REQUIRE(std::equal(out.begin(), out.end(), values.begin()));
+		// and raw pointers are written in place
+		std::fill(back.begin(), back.end(), T(0));
+		s = bytes.data();
+		codec::decode(back.data(), back.data() + n, s);
+		REQUIRE(back == values);
+		REQUIRE(oroch::hip::varint_device_calls() == before + 7);
+	}
 	// below the threshold the loop runs on the host
 	const size_t few = 100;
 	REQUIRE(codec::space(values.begin(), values.begin() + few) > 0);
@@ -700,7 +721,7 @@ static void test_varint_sequences()
 	s = bytes.data();
 	codec::decode(back.begin(), back.begin() + few, s);
 	REQUIRE(s == d && std::equal(back.begin(), back.begin() + few, values.begin()));
-	REQUIRE(oroch::hip::varint_device_calls() == before + 3);
+	REQUIRE(oroch::hip::varint_device_calls() == before + 7);
 }
 
 template <typename T>
