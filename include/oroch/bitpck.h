@@ -6,9 +6,11 @@
 // oroch_unpack_host), which stages it through pinned memory.  Callers that
 // keep data on the device use the C ABI in oroch_hip.h directly.
 //
-// The value codec is fused into the kernels, so only the two the block path
-// uses are accepted: zigzag_codec<T> (the default) and origin_codec<T> or a
-// class derived from it.
+// The kernels fuse the two value codecs the block path uses: zigzag_codec<T>
+// (the default) and origin_codec<T> or a class derived from it.  Any other
+// value codec V (bitpck.h:42 takes any class with value_encode / value_decode)
+// is applied here, value by value on the host, and the images are packed as
+// they are.
 // Interface after Oroch (Copyright (c) 2015 Aleksey Demakov, MIT License); see NOTICE.
 #ifndef OROCH_BITPCK_H_
 #define OROCH_BITPCK_H_
@@ -17,6 +19,7 @@
 #include <iterator>
 
 #include "common.h"
+#include "integer_traits.h"
 #include "origin.h"
 #include "zigzag.h"
 
@@ -24,13 +27,12 @@ namespace oroch {
 
 namespace detail {
 
+// 0: zigzag in the kernel, 1: origin in the kernel, 2: applied on the host
 template <typename T, typename V>
 struct value_codec_kind
 {
-	static_assert(std::is_same<V, zigzag_codec<T>>::value ||
-			      std::is_base_of<origin_codec<T>, V>::value,
-		      "the HIP kernels fuse zigzag_codec or origin_codec only");
-	static constexpr int kind = std::is_base_of<origin_codec<T>, V>::value ? 1 : 0;
+	static constexpr int kind = std::is_base_of<origin_codec<T>, V>::value ? 1
+				    : std::is_same<V, zigzag_codec<T>>::value ? 0 : 2;
 	static uint64_t origin(const V &vcodec)
 	{
 		if constexpr (kind == 1)
@@ -78,10 +80,7 @@ public:
 		if (in.empty()) {
 			std::fill_n(dst, block_size, byte_t(0));
 		} else {
-			using kind = detail::value_codec_kind<T, V>;
-			hip::check(oroch_pack_host(hip::dtype_of<T>(), kind::kind, in.data(), in.size(),
-						   kind::origin(vcodec), unsigned(nbits), dst),
-				   "bitpck_codec::block_encode");
+			pack(in, nbits, vcodec, dst, "bitpck_codec::block_encode");
 		}
 		dst += block_size;
 	}
@@ -113,11 +112,19 @@ public:
 	{
 		using kind = detail::value_codec_kind<T, V>;
 		const uint64_t at = index;
-		T out = T();
-		hip::check(oroch_bitpck_fetch_host(hip::dtype_of<T>(), kind::kind, src, kind::origin(vcodec),
-						   unsigned(nbits), &at, 1, &out),
-			   "bitpck_codec::block_fetch");
-		return out;
+		if constexpr (kind::kind == 2) {
+			unsigned_t image = 0;
+			hip::check(oroch_bitpck_fetch_host(hip::dtype_of<unsigned_t>(), 0, src, 0, unsigned(nbits), &at,
+							   1, &image),
+				   "bitpck_codec::block_fetch");
+			return vcodec.value_decode(image);
+		} else {
+			T out = T();
+			hip::check(oroch_bitpck_fetch_host(hip::dtype_of<T>(), kind::kind, src, kind::origin(vcodec),
+							   unsigned(nbits), &at, 1, &out),
+				   "bitpck_codec::block_fetch");
+			return out;
+		}
 	}
 
 	// bitpck.h:258-266: value `index` of a packed sequence.
@@ -136,10 +143,7 @@ public:
 		const std::vector<T> in = hip::gather<T>(src, end);
 		if (in.empty())
 			return;
-		using kind = detail::value_codec_kind<T, V>;
-		hip::check(oroch_pack_host(hip::dtype_of<T>(), kind::kind, in.data(), in.size(),
-					   kind::origin(vcodec), unsigned(nbits), dst),
-			   "bitpck_codec::encode");
+		pack(in, nbits, vcodec, dst, "bitpck_codec::encode");
 		dst += space(in.size(), nbits);
 	}
 
@@ -151,13 +155,45 @@ public:
 		const size_t n = size_t(std::distance(dst, end));
 		if (n == 0)
 			return;
-		std::vector<T> out(n);
 		using kind = detail::value_codec_kind<T, V>;
-		hip::check(oroch_unpack_host(hip::dtype_of<T>(), kind::kind, src, n, kind::origin(vcodec),
-					     unsigned(nbits), out.data()),
-			   "bitpck_codec::decode");
-		std::copy(out.begin(), out.end(), dst);
+		if constexpr (kind::kind == 2) {
+			std::vector<unsigned_t> images(n);
+			hip::check(oroch_unpack_host(hip::dtype_of<unsigned_t>(), 0, src, n, 0, unsigned(nbits),
+						     images.data()),
+				   "bitpck_codec::decode");
+			for (size_t i = 0; i < n; i++)
+				*dst++ = vcodec.value_decode(images[i]);
+		} else {
+			std::vector<T> out(n);
+			hip::check(oroch_unpack_host(hip::dtype_of<T>(), kind::kind, src, n, kind::origin(vcodec),
+						     unsigned(nbits), out.data()),
+				   "bitpck_codec::decode");
+			std::copy(out.begin(), out.end(), dst);
+		}
 		src += space(n, nbits);
+	}
+
+private:
+	using unsigned_t = typename integer_traits<T>::unsigned_t;
+
+	// The values of `in` packed at dst: through the kernel's own value codec, or as
+	// the images a codec the kernels do not know makes of them (an unsigned
+	// sequence packs as it is).
+	static void pack(const std::vector<T> &in, size_t nbits, value_codec &vcodec, byte_t *dst, const char *what)
+	{
+		using kind = detail::value_codec_kind<T, V>;
+		if constexpr (kind::kind == 2) {
+			std::vector<unsigned_t> images(in.size());
+			for (size_t i = 0; i < in.size(); i++)
+				images[i] = vcodec.value_encode(in[i]);
+			hip::check(oroch_pack_host(hip::dtype_of<unsigned_t>(), 0, images.data(), images.size(), 0,
+						   unsigned(nbits), dst),
+				   what);
+		} else {
+			hip::check(oroch_pack_host(hip::dtype_of<T>(), kind::kind, in.data(), in.size(),
+						   kind::origin(vcodec), unsigned(nbits), dst),
+				   what);
+		}
 	}
 };
 

@@ -302,6 +302,57 @@ static void test_bitpfr_value_codec()
 	REQUIRE(excpts.values[0] == 1);
 }
 
+// bitpck.h:42: any class with value_encode / value_decode serves as the value
+// codec.  One the kernels do not know is applied on the host; the packed bytes are
+// those of its images.
+template <typename T>
+struct flip_codec
+{
+	using U = typename oroch::integer_traits<T>::unsigned_t;
+	U value_encode(T v) const { return U(U(v) ^ U(0x155)); }
+	T value_decode(U u) const { return T(U(u ^ U(0x155))); }
+};
+
+template <typename T>
+static void test_bitpck_custom_value_codec()
+{
+	using U = typename oroch::integer_traits<T>::unsigned_t;
+	using codec = oroch::bitpck_codec<T, flip_codec<T>>;
+	using plain = oroch::bitpck_codec<U>;
+	constexpr size_t N = 1000, BITS = 9;
+	std::vector<T> values(N), back(N);
+	std::vector<U> images(N);
+	flip_codec<T> flip;
+	for (size_t i = 0; i < N; i++) {
+		values[i] = T(rnd() & ((1u << BITS) - 1));
+		images[i] = flip.value_encode(values[i]);
+	}
+	std::vector<uint8_t> bytes(codec::space(N, BITS) + 16, 0xee), want(plain::space(N, BITS));
+	oroch::dst_bytes_t d = bytes.data(), w = want.data();
+	codec::encode(d, values.begin(), values.end(), BITS);
+	plain::encode(w, images.begin(), images.end(), BITS);
+	REQUIRE(size_t(d - bytes.data()) == want.size());
+	REQUIRE(std::equal(want.begin(), want.end(), bytes.begin()));
+	REQUIRE(bytes[want.size()] == 0xee);
+	oroch::src_bytes_t s = bytes.data();
+	codec::decode(back.begin(), back.end(), s, BITS);
+	REQUIRE(size_t(s - bytes.data()) == want.size());
+	REQUIRE(back == values);
+	for (size_t i : {size_t(0), size_t(13), size_t(14), N - 1})
+		REQUIRE(codec::fetch(bytes.data(), i, BITS) == values[i]);
+	// one block at a time
+	uint8_t block[16];
+	d = block;
+	auto it = values.begin();
+	codec::block_encode(d, it, values.end(), BITS, flip);
+	REQUIRE(size_t(it - values.begin()) == codec::capacity(BITS));
+	REQUIRE(std::equal(block, block + 16, want.begin()));
+	std::vector<T> first(codec::capacity(BITS));
+	s = block;
+	codec::block_decode(first.begin(), s, BITS, flip);
+	REQUIRE(std::equal(first.begin(), first.end(), values.begin()));
+}
+
 // tests/unit/bitpfr.cc:32-92: 128 small values, 24 growing powers of two.
 template <typename T>
 static void test_bitpfr_reference_case(T fref)
@@ -742,6 +793,9 @@ int main()
 	oroch::hip::check(oroch_hip_init(0), "oroch_hip_init");
 	test_bitpck_blocks();
 	test_bitpfr_value_codec();
+	test_bitpck_custom_value_codec<int16_t>();
+	test_bitpck_custom_value_codec<uint32_t>();
+	test_bitpck_custom_value_codec<int64_t>();
 	test_bitpfr_reference_case<uint32_t>(1000);
 	test_bitpfr_reference_case<int32_t>(-1000);
 	test_bitpfr_two_calls();
