@@ -573,11 +573,21 @@ __device__ __forceinline__ void put_desc(oroch_block_desc *d, const selection<C>
 	q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// The selection a descriptor holds, from its two 16-byte halves (every lane
+// has loaded the same words).
+template <typename C>
+__device__ __forceinline__ void desc_selection(const uint4 &a, const uint4 &b, selection<C> &sel);
+
 template <typename C>
 __device__ __forceinline__ void get_desc(const oroch_block_desc *d, selection<C> &sel)
 {
 	const uint4 *q = reinterpret_cast<const uint4 *>(d);
-	uint4 a = q[0], b = q[1];
+	desc_selection(q[0], q[1], sel);
+}
+
+template <typename C>
+__device__ __forceinline__ void desc_selection(const uint4 &a, const uint4 &b, selection<C> &sel)
+{
 	sel.origin = C((uint64_t(uniform(a.y)) << 32) | uniform(a.x));
 	sel.dataspace = uniform(a.z);
 	uint32_t w4 = uniform(b.x), w5 = uniform(b.y), w6 = uniform(b.z);
@@ -684,6 +694,9 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 		const C low = nb >= uint32_t(E::W) ? E::MASK : C((C(1) << (nb % E::W)) - 1);
 		C u[VPL];
 		bool f[VPL];
+		// (a field of a 64-bit element that is no wider than 32 bits goes in as a
+		// 32-bit one: two words instead of three, 32-bit shifts)
+		const bool narrow = sizeof(C) == 8 && nb <= 32u;
 #pragma unroll
 		for (int s = 0; s < VPL; s++) {
 			const bool ok = FULL || lane * VPL + s < nv;
@@ -693,7 +706,11 @@ __device__ uint32_t encode_block(const typename E::C (&v)[VPL], int nv, int lane
 				const uint32_t pos = uint32_t(lane * VPL + s);
 				const uint32_t blk = __umulhi(pos, magic);
 				const uint32_t k = pos - blk * cap;
-				lds_or_bits(img, doff * 8u + blk * 128u + k * nb, C(u[s] & low));
+				const uint32_t bit = doff * 8u + blk * 128u + k * nb;
+				if (narrow)
+					lds_or_bits(img, bit, uint32_t(u[s] & low));
+				else
+					lds_or_bits(img, bit, C(u[s] & low));
 			}
 		}
 		if (enc == OROCH_BITPFR) {
@@ -790,56 +807,180 @@ __device__ __forceinline__ void select_any(const typename E::C (&v)[VPL], int nv
 		select_block<E, false>(v, nv, lane, hq, wt, sel);
 }
 
+// One block per wavefront.  The kernel is bound by the latency of its loads (a
+// constant block takes as long as any other), so the values of a wavefront's
+// next block are asked for before the current one is looked at; the loads are
+// unconditional (the last full block is asked for again where there is no next
+// one) and the stores of a block are the same three instructions on every path,
+// so that waiting for the values does not mean waiting for the stores behind
+// them.  A short last block is taken after the loop.
 template <typename E>
-__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select(const typename E::S *src, size_t n,
-								 size_t nblocks, oroch_block_desc *desc,
-								 uint32_t *sizes)
+__device__ __forceinline__ void load_full(const typename E::S *__restrict__ src, size_t blk, int lane,
+					  typename E::C (&v)[VPL])
 {
+	using C = typename E::C;
+	const typename E::S *p = src + blk * BLOCK + size_t(lane) * VPL;
+	if constexpr (E::BYTES == 8) {
+		const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p);
+		const ulonglong2 a = q[0], b = q[1];
+		v[0] = a.x, v[1] = a.y, v[2] = b.x, v[3] = b.y;
+	} else if constexpr (E::BYTES == 4) {
+		const uint4 a = *reinterpret_cast<const uint4 *>(p);
+		v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w;
+	} else if constexpr (E::BYTES == 2) {
+		const uint2 a = *reinterpret_cast<const uint2 *>(p);
+		v[0] = C(a.x & 0xffffu), v[1] = C(a.x >> 16), v[2] = C(a.y & 0xffffu), v[3] = C(a.y >> 16);
+	} else {
+		const uint32_t a = *reinterpret_cast<const uint32_t *>(p);
+		v[0] = C(a & 0xffu), v[1] = C((a >> 8) & 0xffu), v[2] = C((a >> 16) & 0xffu), v[3] = C(a >> 24);
+	}
+}
+
+template <typename E, bool DESC, bool SIZES>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_select(const typename E::S *__restrict__ src, size_t n,
+								 size_t nblocks, oroch_block_desc *__restrict__ desc,
+								 uint32_t *__restrict__ sizes)
+{
+	using C = typename E::C;
 	__shared__ __attribute__((aligned(16))) uint32_t hist2[WAVES_PER_WG][264];
 	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
 	load_width_table(wt);
 	const lane_consts lc = make_lane_consts(wt, lane);
-	for (size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave; blk < nblocks;
-	     blk += size_t(gridDim.x) * WAVES_PER_WG) {
-		const size_t base = blk * BLOCK;
-		const int nv = block_count(n, blk);
-		typename E::C v[VPL];
-		load_block<E>(src, base, nv, lane, v);
-		selection<typename E::C> sel;
-		select_any<E>(v, nv, lane, hist2[wave], wt, lc, sel);
-		if (lane == 0) {
-			if (desc)
-				put_desc(&desc[blk], sel, nv);
-			if (sizes)
-				sizes[blk] = stream_size(sel);
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
+	const size_t nfull = n / BLOCK;
+	size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
+	auto put = [&](size_t at, const selection<C> &sel, int nv) {
+		// Every lane stores the same words to the same place: a store under a
+		// lane condition is branched around, and with a branch the wait for the
+		// next block's values would be a wait for everything, these stores
+		// included.
+		const uint4 a = make_uint4(uint32_t(uint64_t(sel.origin)), uint32_t(uint64_t(sel.origin) >> 32),
+					   sel.dataspace, stream_size(sel));
+		const uint4 b = make_uint4(sel.metaspace | (sel.noutliers << 16),
+					   uint32_t(nv) | (sel.encoding << 16) | (sel.nbits << 24),
+					   sel.ienc | (sel.inbits << 8) | (sel.venc << 16) | (sel.vnbits << 24), 0u);
+		if constexpr (DESC) {
+			uint4 *q = reinterpret_cast<uint4 *>(&desc[at]);
+			q[0] = a;
+			q[1] = b;
 		}
+		if constexpr (SIZES)
+			sizes[at] = a.w;
+	};
+	if (blk < nfull) {
+		// The first block outside the loop, in the loop's own order (values of
+		// the next block asked for, this block selected, its descriptor stored):
+		// the loop is then entered in the state in which it is repeated, and the
+		// wait at its top is for the values alone.
+		C v[VPL], vn[VPL];
+		load_full<E>(src, blk, lane, v);
+		load_full<E>(src, blk + stride < nfull ? blk + stride : blk, lane, vn);
+		{
+			selection<C> sel;
+			select_full<E>(v, lane, hist2[wave], wt, lc, sel);
+			put(blk, sel, BLOCK);
+		}
+		for (blk += stride; blk < nfull; blk += stride) {
+#pragma unroll
+			for (int s = 0; s < VPL; s++)
+				v[s] = vn[s];
+			load_full<E>(src, blk + stride < nfull ? blk + stride : blk, lane, vn);
+			selection<C> sel;
+			select_full<E>(v, lane, hist2[wave], wt, lc, sel);
+			put(blk, sel, BLOCK);
+		}
+	}
+	if (blk == nfull && blk < nblocks) {
+		const int nv = block_count(n, blk);
+		C v[VPL];
+		load_block<E>(src, blk * BLOCK, nv, lane, v);
+		selection<C> sel;
+		select_block<E, false>(v, nv, lane, hist2[wave], wt, sel);
+		put(blk, sel, nv);
 	}
 }
 
+// The image of a full block to the stream in a fixed number of stores per lane,
+// whatever its length: a lane whose 16 bytes lie past the image stores the
+// image's last 16 bytes again (the same bytes to the same place).  A count of
+// stores that does not depend on the block lets the wait for the next block's
+// values leave these stores in flight.
 template <typename E>
-__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode(const typename E::S *src, size_t n,
-								 size_t nblocks,
-								 const oroch_block_desc *desc,
-								 const uint64_t *offsets, uint8_t *dst)
+__device__ __forceinline__ void flush_image_fixed(const uint32_t *img, uint32_t len, uint8_t *dst, int lane)
 {
+	constexpr int ROUNDS = (image_bytes<E>() + WAVE * 16 - 1) / (WAVE * 16);
+	const uint32_t last = ((len + 15u) & ~15u) - 16u; // len >= 1
+	const uint8_t *img8 = reinterpret_cast<const uint8_t *>(img);
+#pragma unroll
+	for (int r = 0; r < ROUNDS; r++) {
+		uint32_t o = uint32_t(lane) * 16u + uint32_t(r) * (WAVE * 16u);
+		o = o < last ? o : last;
+		*reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(img8 + o);
+	}
+}
+
+// One block per wavefront, as k_select: values, descriptor and stream offset
+// of a wavefront's next block are asked for before the current block is
+// encoded, by loads that are issued on every path.
+template <typename E>
+__global__ __launch_bounds__(WAVE *WAVES_PER_WG) void k_encode(const typename E::S *__restrict__ src, size_t n,
+								 size_t nblocks,
+								 const oroch_block_desc *__restrict__ desc,
+								 const uint64_t *__restrict__ offsets,
+								 uint8_t *__restrict__ dst)
+{
+	using C = typename E::C;
 	__shared__ __attribute__((aligned(16))) uint32_t image[WAVES_PER_WG][image_bytes<E>() / 4];
 	__shared__ uint4 wt[65];
 	const int wave = uniform(int(threadIdx.x / WAVE)), lane = lane_id();
 	load_width_table(wt);
-	for (size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave; blk < nblocks;
-	     blk += size_t(gridDim.x) * WAVES_PER_WG) {
-		const size_t base = blk * BLOCK;
+	const size_t stride = size_t(gridDim.x) * WAVES_PER_WG;
+	const size_t nfull = n / BLOCK;
+	size_t blk = size_t(blockIdx.x) * WAVES_PER_WG + wave;
+	// what is fetched ahead for a block
+	struct ahead
+	{
+		C v[VPL];
+		uint4 da, db;
+		uint64_t off;
+	};
+	auto fetch = [&](size_t at, ahead &f) {
+		load_full<E>(src, at, lane, f.v);
+		const uint4 *q = reinterpret_cast<const uint4 *>(desc + at);
+		f.da = q[0];
+		f.db = q[1];
+		f.off = offsets[at];
+	};
+	auto code = [&](const ahead &f) {
+		selection<C> sel;
+		desc_selection(f.da, f.db, sel);
+		const uint32_t len = encode_block<E, true>(f.v, BLOCK, lane, sel, wt, image[wave]);
+		flush_image_fixed<E>(image[wave], len, dst + uniform(f.off), lane);
+		wave_sync();
+	};
+	if (blk < nfull) {
+		// (the first block in the loop's own order, so that the loop is entered in
+		// the state in which it is repeated)
+		ahead cur, nxt;
+		fetch(blk, cur);
+		fetch(blk + stride < nfull ? blk + stride : blk, nxt);
+		code(cur);
+		for (blk += stride; blk < nfull; blk += stride) {
+			cur = nxt;
+			fetch(blk + stride < nfull ? blk + stride : blk, nxt);
+			code(cur);
+		}
+	}
+	if (blk == nfull && blk < nblocks) {
 		const int nv = block_count(n, blk);
-		typename E::C v[VPL];
-		load_block<E>(src, base, nv, lane, v);
-		selection<typename E::C> sel;
+		C v[VPL];
+		load_block<E>(src, blk * BLOCK, nv, lane, v);
+		selection<C> sel;
 		get_desc(&desc[blk], sel);
 		const uint64_t off = uniform(offsets[blk]);
-		const uint32_t len = nv == BLOCK ? encode_block<E, true>(v, nv, lane, sel, wt, image[wave])
-						 : encode_block<E, false>(v, nv, lane, sel, wt, image[wave]);
+		const uint32_t len = encode_block<E, false>(v, nv, lane, sel, wt, image[wave]);
 		flush_image(image[wave], len, dst + off, lane);
-		wave_sync();
 	}
 }
 
@@ -1006,8 +1147,14 @@ static int launch_select(const void *src, size_t n, size_t nb, oroch_block_desc 
 			return int(hipGetLastError());
 		}
 	}
-	hipLaunchKernelGGL(k_select<E>, dim3(grid_for(nb, GRID_SELECT)), dim3(WAVE * WAVES_PER_WG), 0, st,
-			   static_cast<const typename E::S *>(src), n, nb, desc, sizes);
+	const dim3 grid(grid_for(nb, GRID_SELECT)), wg(WAVE * WAVES_PER_WG);
+	const typename E::S *values = static_cast<const typename E::S *>(src);
+	if (desc && sizes)
+		hipLaunchKernelGGL((k_select<E, true, true>), grid, wg, 0, st, values, n, nb, desc, sizes);
+	else if (desc)
+		hipLaunchKernelGGL((k_select<E, true, false>), grid, wg, 0, st, values, n, nb, desc, sizes);
+	else if (sizes)
+		hipLaunchKernelGGL((k_select<E, false, true>), grid, wg, 0, st, values, n, nb, desc, sizes);
 	return int(hipGetLastError());
 }
 

@@ -13,6 +13,7 @@ CASES = {
     "uniform13": lambda: devgen.uniform_bits(1 << 28, torch.int32, 3, 13, dev),
     "int16": lambda: devgen.outlier_mix(1 << 29, torch.int16, 3, dev, body_bits=9, out_bits=15, shift=-200),
     "uint64": lambda: (devgen.outlier_mix(1 << 27, torch.int64, 6, dev, body_bits=20, out_bits=50, shift=1 << 40)).view(torch.uint64),
+    "uint64b": lambda: (devgen.outlier_mix(1 << 28, torch.int64, 3, dev, body_bits=20, out_bits=50, shift=-200) + (1 << 40)).view(torch.uint64),
     "int64mix": lambda: devgen.block_mix_int64(1 << 28, 4, dev),
     "int8": lambda: devgen.outlier_mix(1 << 29, torch.int8, 3, dev, body_bits=4, out_bits=7, shift=-5),
 }
