@@ -158,6 +158,27 @@ def test_fuzz_blocks_against_oracle(hip, oracle, dt):
     assert np.array_equal(back, a)
 
 
+@pytest.mark.parametrize("dt", dg.DTYPES)
+def test_one_block_kernels_agree_for_every_type(hip, oracle, dt):
+    """The one-block-per-wavefront selection and encoder (the 64-bit types' own
+    path; a switch for the others) fetch a wavefront's next block ahead and take
+    a short last block after their loop: the same bytes as the oracle for full
+    blocks, a short last block, fewer blocks than wavefronts and a single value."""
+    rng = np.random.default_rng(2000 + dg.DTYPES.index(dt))
+    blocks = [dg.fuzz_block(rng, dt, 256) for _ in range(700)]
+    for cut in (700 * 256, 699 * 256 + 31, 5 * 256, 3 * 256 + 255, 256, 255, 1):
+        a = np.concatenate(blocks)[:cut]
+        exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+        x = dev(a)
+        with hip.option("select_one_block", 1), hip.option("encode_one_block", 1):
+            stream, offs = hip.group_encode(x)
+            desc = hip.group_select(x)
+        assert np.array_equal(host(offs).astype(np.uint64), exp_offs), cut
+        assert np.array_equal(host(stream), exp), cut
+        assert int(desc[-1]["nvalues"]) == (cut - 1) % 256 + 1
+        assert np.array_equal(host(hip.group_decode(stream, offs, a.size, dt)).view(np.dtype(dt)), a)
+
+
 @pytest.mark.parametrize("dt", [np.uint32, np.int32, np.int64, np.uint8, np.int16])
 def test_whole_sequence_against_oracle(hip, oracle, dt):
     dt = np.dtype(dt)
