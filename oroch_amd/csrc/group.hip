@@ -38,10 +38,10 @@
 #define GRID_DECODE_QUAD 16384u
 #endif
 #ifndef GRID_SELECT
-#define GRID_SELECT 65536u
+#define GRID_SELECT 131072u
 #endif
 #ifndef GRID_ENCODE
-#define GRID_ENCODE 131072u
+#define GRID_ENCODE 262144u
 #endif
 #ifndef GRID_DECODE
 #define GRID_DECODE 262144u
