@@ -57,7 +57,10 @@ while time.time() - t0 < budget:
     a = np.concatenate(blocks)
     exp, exp_offs = oracle.blocks_encode(a, 256, 16)
     x = torch.from_numpy(a).to(dev)
-    stream, offs = oroch_amd.group_encode(x)
+    # (now and then through the one-block kernels, which the 64-bit types always use)
+    one = [int(rng.integers(0, 3) == 0), int(rng.integers(0, 3) == 0)]
+    with oroch_amd.option("select_one_block", one[0]), oroch_amd.option("encode_one_block", one[1]):
+        stream, offs = oroch_amd.group_encode(x)
     ok = np.array_equal(offs.cpu().numpy().astype(np.uint64), exp_offs) and np.array_equal(stream.cpu().numpy(), exp)
     back = oroch_amd.group_decode(stream, offs, a.size, a.dtype)
     ok = ok and np.array_equal(back.cpu().numpy().view(a.dtype), a)
