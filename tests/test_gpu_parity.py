@@ -398,6 +398,74 @@ def test_four_block_decoder_paths(hip, oracle, dt):
         assert np.array_equal(host(hip.group_decode(s2, o2, cut, dt)).view(dt), a[:cut])
 
 
+@pytest.mark.parametrize("dt", [np.uint8, np.int16, np.uint32, np.int32])
+def test_streams_of_one_class_of_block(hip, oracle, dt):
+    """Streams made of one class of block each, of those the four-block kernels
+    treat apart: constant blocks, raw blocks, widths of 1 to 3 bits, more than 16
+    exceptions with bit-packed lists, varint and varfor blocks.  Bytes against the
+    oracle, and both decoders."""
+    import torch
+
+    dt = np.dtype(dt)
+    W = dt.itemsize * 8
+    u = np.dtype("u%d" % dt.itemsize)
+    rng = np.random.default_rng(31 + W + (dt.kind == "u"))
+    lo = -(1 << (W - 1)) if dt.kind == "i" else 0
+    hi = (1 << (W - 1)) - 1 if dt.kind == "i" else (1 << W) - 1
+    nblocks = 40
+
+    def stream_of(kind):
+        out = []
+        for _ in range(nblocks):
+            if kind == "constant":
+                v = np.full(256, int(rng.integers(lo, hi + 1)), np.int64)
+            elif kind == "raw":
+                v = rng.integers(lo, hi + 1, 256).astype(np.int64)
+            elif kind == "narrow":
+                v = rng.integers(0, 1 << int(rng.integers(1, 4)), 256).astype(np.int64) + int(rng.integers(lo, hi - 8))
+            elif kind == "dense":
+                b = max(4, W // 2 - 2)
+                v = rng.integers(0, 1 << b, 256).astype(np.int64)
+                pos = rng.choice(256, int(rng.integers(17, 120)), replace=False)
+                v[pos] = rng.integers(1 << b, 1 << (b + 3), pos.size)
+            else:  # varint / varfor: seven-bit values and a few wide ones
+                v = rng.integers(0, 1 << 7, 256).astype(np.int64)
+                pos = rng.choice(256, int(rng.integers(1, 4)), replace=False)
+                v[pos] = rng.integers(1 << (W - 2), 1 << (W - 1), pos.size)
+                if kind == "varint" and dt.kind == "i":
+                    v -= 1 << 6
+                if kind == "varfor":
+                    v = np.minimum(v + (1 << (W - 2)) + lo, hi)
+            out.append(v)
+        return np.concatenate(out).astype(u).view(dt) if dt.kind == "i" else np.concatenate(out).astype(u)
+
+    # (for the narrower types a plain packing sometimes beats the patched one)
+    want_encoding = {"constant": {0}, "raw": {1}, "narrow": {4, 5}, "dense": {6} if W == 32 else {4, 5, 6},
+                     "varint": {2}, "varfor": {3}}
+    for kind in ("constant", "raw", "narrow", "dense", "varint", "varfor"):
+        if W == 8 and kind in ("varint", "varfor"):
+            continue  # (no block of an 8-bit type is coded as varints)
+        a = stream_of(kind)
+        exp, exp_offs = oracle.blocks_encode(a, 256, 16)
+        x = dev(a)
+        desc = hip.group_select(x)
+        encs = set(int(e) for e in desc["encoding"])
+        assert encs <= want_encoding[kind], (kind, encs)
+        if kind == "narrow":
+            assert int(desc["nbits"].max()) <= 3
+        if kind == "dense":
+            patched = desc[desc["encoding"] == 6]
+            assert W < 32 or len(patched) == nblocks
+            assert len(patched) == 0 or int(patched["noutliers"].min()) > 16
+        stream, offs = hip.group_encode(x)
+        assert np.array_equal(host(offs).astype(np.uint64), exp_offs), kind
+        assert np.array_equal(host(stream), exp), kind
+        back = hip.group_decode(stream, offs, a.size, dt)
+        assert np.array_equal(host(back).view(dt), a), kind
+        with hip.option("decode_one_block", 1):
+            assert torch.equal(hip.group_decode(stream, offs, a.size, dt), back), kind
+
+
 @pytest.mark.parametrize("dt", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32])
 def test_varint_blocks_within_quads(hip, oracle, dt):
     """Blocks coded as varints (zigzag images, or deltas from an origin) in every
