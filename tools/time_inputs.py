@@ -15,6 +15,8 @@ CASES = {
     "uint64": lambda: (devgen.outlier_mix(1 << 27, torch.int64, 6, dev, body_bits=20, out_bits=50, shift=1 << 40)).view(torch.uint64),
     "uint64b": lambda: (devgen.outlier_mix(1 << 28, torch.int64, 3, dev, body_bits=20, out_bits=50, shift=-200) + (1 << 40)).view(torch.uint64),
     "int64mix": lambda: devgen.block_mix_int64(1 << 28, 4, dev),
+    "raw32": lambda: devgen.uniform_bits(1 << 28, torch.int32, 3, 32, dev),
+    "const32": lambda: (torch.arange(1 << 28, dtype=torch.int64, device=dev) >> 8).to(torch.int32),
     "int8": lambda: devgen.outlier_mix(1 << 29, torch.int8, 3, dev, body_bits=4, out_bits=7, shift=-5),
 }
 for name in (sys.argv[1:] or list(CASES)):
