@@ -260,7 +260,9 @@ __device__ __forceinline__ uint32_t decode_quad_fast(const uint32_t *qbuf, uint3
 			ok = ok && scan_rel + 16u <= len;
 	}
 	const uint32_t fast = group_mask(__ballot(ok));
-	if (fast == 0)
+	// (a single block that qualifies is cheaper one block at a time than through
+	// this path, whose cost hardly depends on how many blocks it carries)
+	if ((fast & (fast - 1u)) == 0)
 		return 0;
 
 	// The exceptions of all four blocks first: position and shifted high part

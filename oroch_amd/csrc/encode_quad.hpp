@@ -112,7 +112,9 @@ __device__ __forceinline__ uint32_t encode_quad_fast(const typename E::C (&v)[VP
 	bool ok = (enc == OROCH_BITPCK || enc == OROCH_BITFOR || enc == OROCH_BITPFR) && width_ok &&
 		  dataspace >= pck && size >= list_at && size - list_at <= uint32_t(TAIL_BYTES);
 	const uint32_t fast = group_mask(__ballot(ok));
-	if (fast == 0)
+	// (a single block that qualifies is cheaper one block at a time than through
+	// this path, whose cost hardly depends on how many blocks it carries)
+	if ((fast & (fast - 1u)) == 0)
 		return 0;
 
 	// stream positions relative to the quad's first block
