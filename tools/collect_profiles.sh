@@ -32,6 +32,8 @@ DT=int32 KIND=uniform BODY=13 LOG2N=28 stats int32_uniform13 python3 $R/tools/ti
 DT=int16 KIND=outlier BODY=9 OUT=16 PERMILLE=5 SHIFT=-256 SEED=5 LOG2N=28 stats int16_config5 python3 $R/tools/time_any.py
 stats sequences python3 $R/tools/time_sequences.py
 grep -h "frac of 8TB/s\|of 8 TB/s" $DEST/int16.log $DEST/uint64.log $DEST/int32_uniform13.log $DEST/int16_config5.log $DEST/sequences.log > $DEST/${TAG}_other_inputs.txt
-# the bench as the driver runs it (no profiler): the line with every part
+# the bench as the driver runs it (no profiler): the line with every part, the traffic
+# just measured included (the box's copy of profiles/ gets the new record)
+mkdir -p $R/profiles && cp $DEST/traffic_int32_2p30.json $R/profiles/
 cd $R && timeout -k 10 600 python3 bench.py > $DEST/${TAG}_bench_plain.json 2> $DEST/bench_plain.err
 ls -la $DEST
