@@ -120,7 +120,33 @@ def cpu_whole_arrays(po, dg):
     return out
 
 
-def cpu_baseline(log2n, seed, config="headline", native_child=False):
+def cpu_native_baseline(log2n, config):
+    """The CPU baseline once more with the reference built at -O3 -march=native of
+    the machine that built the checker, in a child process (a host without those
+    instructions only loses this figure).  Called before this process touches
+    the GPU: no child is started from a process that has initialised it."""
+    native = os.path.join(ROOT, "oracle", "_ref", "liboroch_ref_native.so")
+    if not os.path.exists(native):
+        return None
+    import subprocess
+
+    arch = "unknown"
+    try:
+        arch = open(os.path.join(ROOT, "oracle", "_ref", "native_arch.txt")).read().strip()
+    except OSError:
+        pass
+    env = dict(os.environ, OROCH_REF_LIBRARY=os.path.join("_ref", "liboroch_ref_native.so"))
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-native-child",
+                        "--cpu-log2n", str(min(log2n, 26)), "--config", config],
+                       env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode == 0 and lines:
+        return dict(json.loads(lines[-1]), built_for=arch, sample="2^%d values, otherwise as above" % min(log2n, 26))
+    return {"value": None, "built_for": arch,
+            "note": "did not run on this host (exit %d): built for another CPU" % r.returncode}
+
+
+def cpu_baseline(log2n, seed, config="headline", native_child=False, native=None):
     """The reference's own code (oracle/_ref) -- or the C port -- on host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import datagen as dg
@@ -150,29 +176,8 @@ def cpu_baseline(log2n, seed, config="headline", native_child=False):
                       "reference's bitpck / bitfor / bitpfr with the caller's parameters on 2^24 "
                       "values, one thread" % (log2n, name, threads, nproc),
         }
-        # the same at -O3 -march=native of the machine that built the checker, in
-        # a child process: a host without those instructions only loses this figure
-        native = os.path.join(ROOT, "oracle", "_ref", "liboroch_ref_native.so")
-        if os.path.exists(native):
-            import subprocess
-
-            arch = "unknown"
-            try:
-                arch = open(os.path.join(ROOT, "oracle", "_ref", "native_arch.txt")).read().strip()
-            except OSError:
-                pass
-            env = dict(os.environ, OROCH_REF_LIBRARY=os.path.join("_ref", "liboroch_ref_native.so"))
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-native-child",
-                                "--cpu-log2n", str(min(log2n, 26)), "--config", config],
-                               env=env, capture_output=True, text=True, timeout=300)
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode == 0 and lines:
-                out["O3_march_native"] = dict(json.loads(lines[-1]), built_for=arch,
-                                              sample="2^%d values, otherwise as above" % min(log2n, 26))
-            else:
-                out["O3_march_native"] = {"value": None, "built_for": arch,
-                                          "note": "did not run on this host (exit %d): built for another "
-                                                  "CPU" % r.returncode}
+        if native is not None:
+            out["O3_march_native"] = native
         return out
     o = po.oracle
     t0 = time.perf_counter()
@@ -427,6 +432,11 @@ def main():
                "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # (child processes first, before this one initialises the GPU)
+    native = None
+    if world == 1 and not args.no_cpu_baseline:
+        native = cpu_native_baseline(args.cpu_log2n, args.config)
+
     import torch
     import torch.distributed as dist
 
@@ -600,7 +610,7 @@ def main():
         if e2e is not None:
             line["end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed, args.config)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed, args.config, native=native)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
